@@ -1,0 +1,114 @@
+"""ctypes binding of libgram_hip.so (include/gram_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent, the
+import fails loudly.  Build it with ``python -c 'import __graft_entry__ as g; g.build()'`` or
+``make -C gram_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgram_hip.so")
+
+GRAM_MAX_BEAMS = 64
+GRAM_MAX_DEC_LEN = 32
+GRAM_MAX_PASSAGE_LEN = 128
+EPI_BF16, EPI_BF16_RELU, EPI_F32_ADD, EPI_F32, EPI_KV_BANK = range(5)
+E_ARG, E_WORKSPACE, E_BEAM = -1, -2, -3
+
+vp = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+
+
+class KVBank(C.Structure):
+    _fields_ = [("k", vp), ("vt", vp), ("n_layers", i32), ("B", i32), ("H", i32), ("S", i32)]
+
+
+class Trie(C.Structure):
+    _fields_ = [("child_off", vp), ("child_tok", vp), ("child_node", vp), ("n_nodes", i32), ("n_edges", i32),
+                ("max_fanout", i32)]
+
+
+class BeamState(C.Structure):
+    _fields_ = [("B", i32), ("K", i32), ("Tmax", i32), ("length_penalty", f32), ("eos", i32), ("pad", i32),
+                ("tokens", vp), ("node", vp), ("beam_scores", vp), ("seq", vp), ("anc", vp), ("done", vp),
+                ("n_hyps", vp), ("hyp_score", vp), ("worst", vp), ("hyp_len", vp), ("hyp_tok", vp), ("error", vp)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("vocab", i32), ("d_model", i32), ("d_ff", i32), ("n_heads", i32), ("n_enc_layers", i32),
+        ("n_dec_layers", i32), ("max_passages", i32), ("tie_word_embeddings", i32),
+        ("use_position_embedding", i32), ("eps", f32),
+        ("embed_f32", vp), ("lm_head_bf16", vp), ("pos_emb_f32", vp), ("enc_bias_f32", vp), ("dec_bias_f32", vp),
+        ("enc_final_ln", vp), ("dec_final_ln", vp),
+        ("enc_ln1", C.POINTER(vp)), ("enc_wqkv", C.POINTER(vp)), ("enc_wo", C.POINTER(vp)),
+        ("enc_ln2", C.POINTER(vp)), ("enc_wi", C.POINTER(vp)), ("enc_wo2", C.POINTER(vp)),
+        ("dec_ln1", C.POINTER(vp)), ("dec_wqkv", C.POINTER(vp)), ("dec_wo", C.POINTER(vp)),
+        ("dec_ln2", C.POINTER(vp)), ("dec_wq_x", C.POINTER(vp)), ("dec_wo_x", C.POINTER(vp)),
+        ("dec_ln3", C.POINTER(vp)), ("dec_wi", C.POINTER(vp)), ("dec_wo2", C.POINTER(vp)),
+        ("dec_wkv_x_all", vp),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/gram_hip.h declares
+SIGNATURES = {
+    "gram_abi_version": (C.c_int, []),
+    "gram_gemm_bf16": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KVBank), vp]),
+    "gram_embed_i64": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "gram_embed_i32": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "gram_rmsnorm_bf16": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, f32, f32, vp, C.c_int, C.c_int, vp]),
+    "gram_enc_self_attn": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "gram_cross_attn_decode": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "gram_dec_self_attn": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "gram_row_lse": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "gram_beam_init": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), C.c_int, vp]),
+    "gram_beam_step": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), vp, vp, C.c_int, C.c_int, vp]),
+    "gram_beam_finalize": (C.c_int, [C.POINTER(BeamState), C.c_int, C.c_int, vp, vp, vp, vp]),
+    "gram_model_create": (vp, [C.POINTER(ModelDesc)]),
+    "gram_model_destroy": (None, [vp]),
+    "gram_workspace_bytes": (i64, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gram_encode_fused": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, C.c_int, vp, vp]),
+    "gram_decode_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
+    "gram_generate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.POINTER(Trie),
+                                vp, i64, vp, vp, C.POINTER(i32), vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libgram_hip.so and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build() or "
+            "`make -C gram_amd/csrc`).  gram_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gram_abi_version() != 1:
+        raise ImportError("libgram_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class GramHipError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str) -> None:
+    if code == 0:
+        return
+    names = {E_ARG: "GRAM_E_ARG (bad shape / unsupported size)", E_WORKSPACE: "GRAM_E_WORKSPACE",
+             E_BEAM: "GRAM_E_BEAM (impossible beam state; HF would raise here)"}
+    raise GramHipError(f"{what} failed: {names.get(code, f'hipError {code}')}")

@@ -1,0 +1,351 @@
+// beam.hip -- Trie-constrained beam search state machine on the device.
+//
+// Replaces, per decode step and per user (reference call site gram.py:93-99, kwargs
+// single_runner_gram.py:641-651; third-party transformers==4.26.0 semantics, restated in
+// oracle/gram_oracle.py::beam_search):
+//   log_softmax                      -> logits[tok] - lse[row]            (lse from rowops.hip)
+//   PrefixConstrainedLogitsProcessor -> children of the beam's Trie node (flat CSR in HBM);
+//                                       the per-beam Python callback of generation_trie.py:89-95
+//                                       (one D2H sync per beam per step) disappears
+//   + beam_scores, topk(2K) over K*V -> bitonic sort in LDS of the <= K*max_fanout finite
+//                                       candidates (64-bit keys: orderable score | ~flat index,
+//                                       so ties resolve to the lower flat index) + -inf fillers
+//   BeamSearchScorer.process         -> one thread walks the 2K ranked candidates
+//   input_ids gather / _reorder_cache-> sequences and the self-attention ancestor table are
+//                                       advanced in place; K/V caches are never moved
+// One workgroup per user; users are independent, so this shards trivially.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+// index of tok among node's children, or -1
+__device__ int find_child(const gram_trie_t& tr, int node, int tok) {
+  if (node < 0) return -1;
+  int lo = tr.child_off[node], hi = tr.child_off[node + 1];
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    int v = tr.child_tok[mid];
+    if (v == tok) return mid;
+    if (v < tok) lo = mid + 1; else hi = mid;
+  }
+  return -1;
+}
+
+__device__ double norm_len(int len, float lp) {
+  if (lp == 1.0f) return (double)len;
+  if (lp == 0.0f) return 1.0;
+  return pow((double)len, (double)lp);
+}
+
+// BeamHypotheses.add (list semantics: append, drop the minimum, later elements shift down)
+__device__ void hyp_add(const gram_beam_state_t& st, int b, const int32_t* toks, int len, float sum_logprobs) {
+  const int K = st.K, T = st.Tmax;
+  double* hs = st.hyp_score + (size_t)b * (K + 1);
+  int32_t* hl = st.hyp_len + (size_t)b * (K + 1);
+  int32_t* ht = st.hyp_tok + (size_t)b * (K + 1) * T;
+  int n = st.n_hyps[b];
+  const double score = (double)sum_logprobs / norm_len(len, st.length_penalty);
+  if (n < K || score > st.worst[b]) {
+    hs[n] = score;
+    hl[n] = len;
+    for (int i = 0; i < len; ++i) ht[(size_t)n * T + i] = toks[i];
+    ++n;
+    if (n > K) {
+      // sorted([(s, idx)]): minimum score, ties -> lowest index; worst = second smallest
+      int imin = 0;
+      for (int i = 1; i < n; ++i)
+        if (hs[i] < hs[imin]) imin = i;
+      double second = 1e300;
+      bool have = false;
+      for (int i = 0; i < n; ++i) {
+        if (i == imin) continue;
+        if (!have || hs[i] < second) { second = hs[i]; have = true; }
+      }
+      for (int i = imin; i + 1 < n; ++i) {
+        hs[i] = hs[i + 1];
+        hl[i] = hl[i + 1];
+        for (int p = 0; p < T; ++p) ht[(size_t)i * T + p] = ht[(size_t)(i + 1) * T + p];
+      }
+      --n;
+      st.worst[b] = second;
+    } else {
+      st.worst[b] = score < st.worst[b] ? score : st.worst[b];
+    }
+    st.n_hyps[b] = n;
+  }
+}
+
+__global__ void beam_init_kernel(gram_beam_state_t st, gram_trie_t tr, int start) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int R = st.B * st.K;
+  if (r == 0) st.error[0] = 0;
+  if (r < st.B) {
+    st.done[r] = 0;
+    st.n_hyps[r] = 0;
+    st.worst[r] = 1e9;
+  }
+  if (r >= R) return;
+  st.tokens[r] = start;
+  st.beam_scores[r] = (r % st.K) == 0 ? 0.f : -1e9f;
+  for (int p = 0; p < st.Tmax; ++p) {
+    st.seq[(size_t)r * st.Tmax + p] = p == 0 ? start : 0;
+    st.anc[(size_t)p * R + r] = r;
+  }
+  const int e = find_child(tr, 0, start);
+  st.node[r] = e < 0 ? -1 : tr.child_node[e];
+}
+
+__global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gram_trie_t tr, const float* __restrict__ logits,
+                                                        const float* __restrict__ lse, int V, int cur_len, int nc_max) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [nc_max]
+  __shared__ int s_pre[GRAM_MAX_BEAMS + 1];
+  __shared__ int s_C, s_NC, s_isdone;
+  __shared__ float sel_score[GRAM_MAX_BEAMS];
+  __shared__ int sel_tok[GRAM_MAX_BEAMS], sel_par[GRAM_MAX_BEAMS], sel_node[GRAM_MAX_BEAMS];
+  __shared__ int new_seq[GRAM_MAX_BEAMS * GRAM_MAX_DEC_LEN];
+  __shared__ int new_anc[GRAM_MAX_DEC_LEN * GRAM_MAX_BEAMS];
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int K = st.K, T = st.Tmax, R = st.B * K;
+  const int row0 = b * K;
+  const int t = cur_len - 1;  // decode step whose K/V were just written
+
+  if (tid == 0) {
+    s_isdone = st.done[b];
+    int acc = 0;
+    for (int k = 0; k < K; ++k) {
+      s_pre[k] = acc;
+      const int nd = st.node[row0 + k];
+      acc += (s_isdone || nd < 0) ? 0 : (tr.child_off[nd + 1] - tr.child_off[nd]);
+    }
+    s_pre[K] = acc;
+    s_C = acc;
+    int nc = 64;
+    while (nc < acc) nc <<= 1;
+    s_NC = nc;
+    if (acc > nc_max) { st.error[0] = 2; s_C = 0; s_NC = 64; s_pre[K] = 0; }
+  }
+  __syncthreads();
+  const int C = s_C, NC = s_NC;
+  const bool isdone = s_isdone != 0;
+
+  if (!isdone) {
+    // gather: log_softmax at the allowed tokens + running beam score
+    for (int ci = tid; ci < NC; ci += 256) {
+      unsigned long long key = 0ull;
+      if (ci < C) {
+        int k = 0;
+        while (s_pre[k + 1] <= ci) ++k;
+        const int r = row0 + k;
+        const int e = tr.child_off[st.node[r]] + (ci - s_pre[k]);
+        const int tok = tr.child_tok[e];
+        const float sc = (logits[(size_t)r * V + tok] - lse[r]) + st.beam_scores[r];
+        key = ((unsigned long long)f2ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(k * V + tok));
+      }
+      keys[ci] = key;
+    }
+    __syncthreads();
+    // bitonic sort, descending
+    for (int kk = 2; kk <= NC; kk <<= 1) {
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < NC; i += 256) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long a = keys[i], c = keys[ixj];
+            const bool desc = (i & kk) == 0;
+            if (desc ? (a < c) : (a > c)) {
+              keys[i] = c;
+              keys[ixj] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  if (tid == 0) {
+    if (isdone) {
+      // BeamSearchScorer.process pads a finished user
+      for (int j = 0; j < K; ++j) {
+        sel_score[j] = 0.f;
+        sel_tok[j] = st.pad;
+        sel_par[j] = j;
+        sel_node[j] = -1;
+      }
+    } else {
+      int j = 0;
+      int ftok = 0;  // next filler token candidate (beam 0, -inf), ascending flat index
+      const int node0 = st.node[row0];
+      float best = -INFINITY;
+      for (int rank = 0; rank < 2 * K && j < K; ++rank) {
+        float sc;
+        int k, tok;
+        if (rank < C) {
+          const unsigned long long key = keys[rank];
+          sc = ord2f((uint32_t)(key >> 32));
+          const uint32_t flat = 0xffffffffu - (uint32_t)(key & 0xffffffffull);
+          k = (int)(flat / (uint32_t)V);
+          tok = (int)(flat % (uint32_t)V);
+        } else {
+          while (ftok < V && find_child(tr, node0, ftok) >= 0) ++ftok;
+          sc = -INFINITY;
+          k = 0;
+          tok = ftok++;
+        }
+        if (rank == 0) best = sc;
+        if (tok == st.eos) {
+          if (rank >= K) continue;
+          hyp_add(st, b, st.seq + (size_t)(row0 + k) * T, cur_len, sc);
+        } else {
+          const int e = (rank < C) ? find_child(tr, st.node[row0 + k], tok) : -1;
+          sel_score[j] = sc;
+          sel_tok[j] = tok;
+          sel_par[j] = k;
+          sel_node[j] = e < 0 ? -1 : tr.child_node[e];
+          ++j;
+        }
+      }
+      if (j < K) {
+        st.error[0] = 1;  // HF raises ValueError here
+        for (; j < K; ++j) { sel_score[j] = -INFINITY; sel_tok[j] = st.pad; sel_par[j] = 0; sel_node[j] = -1; }
+      }
+      // BeamHypotheses.is_done(best_sum_logprobs = next_scores.max(), cur_len)
+      if (st.n_hyps[b] >= K) {
+        const double cur = (double)best / norm_len(cur_len, st.length_penalty);
+        if (st.worst[b] >= cur) st.done[b] = 1;
+      }
+    }
+  }
+  __syncthreads();
+
+  // advance sequences / ancestor table / per-row state (read old -> LDS -> write)
+  for (int idx = tid; idx < K * T; idx += 256) {
+    const int j = idx / T, p = idx - j * T;
+    int v = 0;
+    if (p < cur_len) v = st.seq[(size_t)(row0 + sel_par[j]) * T + p];
+    else if (p == cur_len) v = sel_tok[j];
+    new_seq[idx] = v;
+  }
+  for (int idx = tid; idx < T * K; idx += 256) {
+    const int p = idx / K, j = idx - p * K;
+    int v;
+    if (p < t) v = st.anc[(size_t)p * R + row0 + sel_par[j]];
+    else if (p == t) v = row0 + sel_par[j];
+    else v = row0 + j;
+    new_anc[idx] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < K * T; idx += 256) st.seq[(size_t)row0 * T + idx] = new_seq[idx];
+  for (int idx = tid; idx < T * K; idx += 256) {
+    const int p = idx / K, j = idx - p * K;
+    st.anc[(size_t)p * R + row0 + j] = new_anc[idx];
+  }
+  if (tid < K) {
+    st.beam_scores[row0 + tid] = sel_score[tid];
+    st.tokens[row0 + tid] = sel_tok[tid];
+    st.node[row0 + tid] = sel_node[tid];
+  }
+}
+
+__global__ void beam_finalize_kernel(gram_beam_state_t st, int nret, int max_length, int cur_len, int64_t* __restrict__ sequences,
+                                     float* __restrict__ scores, int32_t* __restrict__ out_width) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const int K = st.K, T = st.Tmax;
+  if (!st.done[b]) {
+    for (int k = 0; k < K; ++k) {
+      const int r = b * K + k;
+      hyp_add(st, b, st.seq + (size_t)r * T, cur_len, st.beam_scores[r]);
+    }
+  }
+  const int n = st.n_hyps[b];
+  const double* hs = st.hyp_score + (size_t)b * (K + 1);
+  const int32_t* hl = st.hyp_len + (size_t)b * (K + 1);
+  const int32_t* ht = st.hyp_tok + (size_t)b * (K + 1) * T;
+  unsigned long long taken = 0ull;  // K+1 <= 65 entries; n <= K <= 64 here
+  int maxlen = 0;
+  for (int j = 0; j < nret; ++j) {
+    int64_t* dst = sequences + ((size_t)b * nret + j) * max_length;
+    for (int p = 0; p < max_length; ++p) dst[p] = st.pad;
+    if (j >= n) {  // sorted_hyps.pop() on an empty list: IndexError in HF
+      st.error[0] = 3;
+      scores[b * nret + j] = -INFINITY;
+      continue;
+    }
+    // sorted(beams, key=score) ascending + pop(): best score, ties -> highest list index
+    int best = -1;
+    for (int i = 0; i < n; ++i) {
+      if (taken & (1ull << i)) continue;
+      if (best < 0 || hs[i] >= hs[best]) best = i;
+    }
+    taken |= 1ull << best;
+    const int len = hl[best];
+    for (int p = 0; p < len && p < max_length; ++p) dst[p] = ht[(size_t)best * T + p];
+    if (len < max_length) dst[len] = st.eos;
+    scores[b * nret + j] = (float)hs[best];
+    maxlen = len > maxlen ? len : maxlen;
+  }
+  int w = maxlen + 1;
+  if (w > max_length) w = max_length;
+  atomicMax(out_width, w);
+}
+
+}  // namespace
+
+static int check_state(const gram_beam_state_t* st) {
+  if (!st || st->B < 1 || st->K < 1 || st->K > GRAM_MAX_BEAMS || st->Tmax < 2 || st->Tmax > GRAM_MAX_DEC_LEN) return GRAM_E_ARG;
+  return 0;
+}
+
+extern "C" int gram_beam_init(const gram_beam_state_t* st, const gram_trie_t* tr, int start_token, void* stream) {
+  if (int e = check_state(st)) return e;
+  if (!tr) return GRAM_E_ARG;
+  const int R = st->B * st->K;
+  hipLaunchKernelGGL(beam_init_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, *st, *tr, start_token);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gram_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, const float* lse, int V,
+                              int cur_len, void* stream) {
+  if (int e = check_state(st)) return e;
+  if (!tr || cur_len < 1 || cur_len >= st->Tmax || V < 2) return GRAM_E_ARG;
+  long long need = (long long)st->K * tr->max_fanout;
+  int nc = 64;
+  while (nc < need) nc <<= 1;
+  const size_t smem = (size_t)nc * 8;
+  if (smem > 128 * 1024) return GRAM_E_ARG;
+  static size_t attr_bytes = 0;
+  if (smem > attr_bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_bytes = smem;
+  }
+  hipLaunchKernelGGL(beam_step_kernel, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gram_beam_finalize(const gram_beam_state_t* st, int nret, int max_length, int64_t* sequences, float* scores,
+                                  int32_t* out_width, void* stream) {
+  if (int e = check_state(st)) return e;
+  if (nret < 1 || nret > st->K || max_length != st->Tmax) return GRAM_E_ARG;
+  hipError_t e = hipMemsetAsync(out_width, 0, sizeof(int32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(beam_finalize_kernel, dim3(st->B), dim3(64), 0, (hipStream_t)stream, *st, nret, max_length, max_length,
+                     sequences, scores, out_width);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,47 @@
+// common.h -- shared device helpers for libgram_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gram_hip.h"
+
+typedef __bf16 bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GRAM_FMIN (-3.4028234663852886e38f)  // torch.finfo(float32).min, gram_t5_modeling.py:1130-1132
+#define WAVE 64
+
+#define GRAM_CHECK_LAUNCH()                       \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+// D[16x16] += A[16x32] * B[32x16]; lane l supplies A[row l&15][k 8(l>>4)..+7], B[k 8(l>>4)..+7][col l&15];
+// lane l receives D[row 4(l>>4)+j][col l&15] in element j.
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 ld_global_b128(const bf16* p) {
+  return *reinterpret_cast<const bf16x8*>(p);
+}
+
+__device__ __forceinline__ bf16x8 zero_bf16x8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16)0.0f;
+  return z;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,260 @@
+// dec_attn.hip -- the two decoder attention kernels of one decode step.
+//
+// (1) cross_attn_kernel: late-fusion cross-attention, THE HBM-bound kernel of the path.
+//     Reference: T5Attention.forward cross branch, gram_t5_modeling.py:531-534,547-549,572-622
+//     (zero position bias :577-582, additive mask :1145-1147), called per layer per step on
+//     K-times replicated K/V.  Here ONE bank per user is streamed ONCE per (layer, step) and
+//     shared by all of the user's beams: algorithmic bytes = 2 * S * 64 * 2 B per (user, head).
+//
+//     Mapping: one workgroup per (user, head), 4 waves, wave w owns the 32-key steps
+//     w, w+4, ...  Per step a wave issues 8 x 16-byte-per-lane global loads (K rows as the
+//     MFMA A operand, V^T rows as the A operand of the second product -- both k-contiguous in
+//     the bank layouts of gram_hip.h, so nothing is transposed on chip), software-pipelined one
+//     step ahead (two named register sets).  S^T = K Q^T puts a beam on a lane column, so the
+//     online softmax is in-register + two cross-lane steps, and exp(S^T) is directly the B
+//     operand of O^T = V^T P^T (same row-permutation trick as enc_attn.hip).  Waves merge their
+//     (m, l, O) partials through LDS at the end.
+//
+// (2) dec_self_attn_kernel: causal self-attention of the newest token over <= 32 cached
+//     positions with beam-parent indirection (anc table) instead of the reference's
+//     torch.cat + index_select of the whole cache (gram_t5_modeling.py:536-540,
+//     gram_t5.py:320-348); unidirectional relative bias, last query row (:586-593).
+#include "common.h"
+
+namespace {
+
+struct StepRegs {
+  bf16x8 kf[2][2];
+  bf16x8 vf[4];
+  uint2 mk;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
+    const bf16* __restrict__ q, const bf16* __restrict__ kbank, const bf16* __restrict__ vtbank,
+    const uint8_t* __restrict__ mask, bf16* __restrict__ out, int K, int H, int S) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NB = NT * 16;                               // padded beams
+  float* sm_m = reinterpret_cast<float*>(smem);             // [4][NB]
+  float* sm_l = sm_m + 4 * NB;                              // [4][NB]
+  float* sm_o = sm_l + 4 * NB;                              // [4][NB][64]
+
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int inner = H * 64;
+  const bf16* kb = kbank + ((size_t)b * H + h) * S * 64;
+  const bf16* vt = vtbank + ((size_t)b * H + h) * 64 * S;
+  const uint8_t* mk = mask + (size_t)b * S;
+
+  bf16x8 qf[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int beam = 16 * nt + c;
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+      qf[nt][kd] = beam < K ? ld_global_b128(q + ((size_t)b * K + beam) * inner + h * 64 + 32 * kd + 8 * g) : zero_bf16x8();
+  }
+
+  f32x4 o[4][NT];
+  float m[NT], l[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    m[nt] = GRAM_FMIN;
+    l[nt] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) o[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int krow = 8 * (c >> 2) + (c & 3);  // + 4t: key row of S^T tile t this lane feeds
+  auto load = [&](StepRegs& r, int step) {
+    const bf16* kp = kb + (size_t)(32 * step + krow) * 64 + 8 * g;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kd = 0; kd < 2; ++kd) r.kf[t][kd] = ld_global_b128(kp + t * 4 * 64 + 32 * kd);
+    const bf16* vp = vt + (size_t)c * S + 32 * step + 8 * g;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) r.vf[mt] = ld_global_b128(vp + (size_t)16 * mt * S);
+    r.mk = *reinterpret_cast<const uint2*>(mk + 32 * step + 8 * g);
+  };
+  auto compute = [&](const StepRegs& r) {
+    bf16x8 pf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        a = mfma16(r.kf[t][0], qf[nt][0], a);
+        a = mfma16(r.kf[t][1], qf[nt][1], a);
+        const uint32_t mb = t == 0 ? r.mk.x : r.mk.y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = ((mb >> (8 * j)) & 0xffu) ? a[j] : GRAM_FMIN;
+        s[t] = a;
+      }
+      float tm = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
+                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+      tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+      const float mn = fmaxf(m[nt], tm);
+      const float alpha = __expf(m[nt] - mn);
+      m[nt] = mn;
+      float ps = 0.f;
+      bf16x8 f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float e = __expf(s[t][j] - mn);
+          ps += e;
+          f[4 * t + j] = (bf16)e;
+        }
+      pf[nt] = f;
+      l[nt] = l[nt] * alpha + ps;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) o[mt][nt] *= alpha;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[mt][nt] = mfma16(r.vf[mt], pf[nt], o[mt][nt]);
+  };
+
+  const int nsteps = S >> 5;
+  StepRegs ra, rb;
+  int i = wave;
+  if (i < nsteps) load(ra, i);
+  while (i < nsteps) {
+    int nx = i + 4;
+    if (nx < nsteps) load(rb, nx);
+    compute(ra);
+    i = nx;
+    if (i >= nsteps) break;
+    nx = i + 4;
+    if (nx < nsteps) load(ra, nx);
+    compute(rb);
+    i = nx;
+  }
+
+  // merge the four waves' partials
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float lt = l[nt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const int beam = 16 * nt + c;
+    if (g == 0) {
+      sm_m[wave * NB + beam] = m[nt];
+      sm_l[wave * NB + beam] = lt;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      *reinterpret_cast<f32x4*>(sm_o + ((size_t)(wave * NB + beam)) * 64 + 16 * mt + 4 * g) = o[mt][nt];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < K * 16; idx += 256) {
+    const int beam = idx >> 4, d4 = (idx & 15) * 4;
+    float M = GRAM_FMIN;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, sm_m[w * NB + beam]);
+    float Lsum = 0.f;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float wgt = __expf(sm_m[w * NB + beam] - M);
+      Lsum += sm_l[w * NB + beam] * wgt;
+      acc += *reinterpret_cast<const f32x4*>(sm_o + ((size_t)(w * NB + beam)) * 64 + d4) * wgt;
+    }
+    const float inv = 1.f / Lsum;
+    bf16x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (bf16)(acc[e] * inv);
+    *reinterpret_cast<bf16x4*>(out + ((size_t)b * K + beam) * inner + h * 64 + d4) = r;
+  }
+}
+
+template <int NT>
+int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int S,
+                 hipStream_t st) {
+  const size_t smem = (size_t)(2 * 4 * NT * 16 + 4 * NT * 16 * 64) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_kernel<NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cross_attn_kernel<NT>, dim3(H, B), dim3(256), smem, st, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
+                     mask, (bf16*)out, K, H, S);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kcache,
+                                                            bf16* __restrict__ vcache, const int32_t* __restrict__ anc,
+                                                            const float* __restrict__ bias, bf16* __restrict__ out, int R,
+                                                            int H, int t) {
+  const int r = blockIdx.x, i = threadIdx.x;  // i: 16 threads per head, 4 dims each
+  const int inner = H * 64, h = i >> 4;
+  const bf16* row = qkv + (size_t)r * 3 * inner + 4 * i;
+  const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(row);
+  const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(row + inner);
+  const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(row + 2 * inner);
+  *reinterpret_cast<bf16x4*>(kcache + ((size_t)t * R + r) * inner + 4 * i) = k4;
+  *reinterpret_cast<bf16x4*>(vcache + ((size_t)t * R + r) * inner + 4 * i) = v4;
+  float qf[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) qf[e] = (float)q4[e];
+  float m = -INFINITY, l = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j <= t; ++j) {
+    bf16x4 kj = k4, vj = v4;
+    if (j < t) {
+      const int a = anc[(size_t)j * R + r];
+      kj = *reinterpret_cast<const bf16x4*>(kcache + ((size_t)j * R + a) * inner + 4 * i);
+      vj = *reinterpret_cast<const bf16x4*>(vcache + ((size_t)j * R + a) * inner + 4 * i);
+    }
+    float s = qf[0] * (float)kj[0] + qf[1] * (float)kj[1] + qf[2] * (float)kj[2] + qf[3] * (float)kj[3];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    s += bias[h * GRAM_MAX_DEC_LEN + (t - j)];
+    const float mn = fmaxf(m, s);
+    const float alpha = __expf(m - mn);
+    const float p = __expf(s - mn);
+    m = mn;
+    l = l * alpha + p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = acc[e] * alpha + p * (float)vj[e];
+  }
+  const float inv = 1.f / l;
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[e] * inv);
+  *reinterpret_cast<bf16x4*>(out + (size_t)r * inner + 4 * i) = o;
+}
+
+}  // namespace
+
+extern "C" int gram_cross_attn_decode(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
+                                      int B, int K, int H, int S, void* stream) {
+  if (B < 1 || K < 1 || K > GRAM_MAX_BEAMS || H < 1 || S < 32 || (S & 31)) return GRAM_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  switch ((K + 15) / 16) {
+    case 1: return launch_cross<1>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
+    case 2: return launch_cross<2>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
+    case 3: return launch_cross<3>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
+    default: return launch_cross<4>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
+  }
+}
+
+extern "C" int gram_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias, void* out,
+                                  int R, int H, int t, int Tmax, void* stream) {
+  if (R < 1 || H < 1 || H > 16 || t < 0 || t >= Tmax || Tmax > GRAM_MAX_DEC_LEN) return GRAM_E_ARG;
+  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(R), dim3(H * 16), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)kcache,
+                     (bf16*)vcache, anc, bias, (bf16*)out, R, H, t);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,207 @@
+// gemm.hip -- C[M,N] (+)= A[M,K] @ W[N,K]^T on MFMA (bf16 in, fp32 accumulate), gfx950.
+//
+// Replaces every nn.Linear of the path (reference: gram_t5_modeling.py:300-301,369-372,
+// gram_t5.py:254).  Both operands are K-contiguous ("NT" GEMM), which is exactly the MFMA
+// fragment shape: lane (r = l&15, g = l>>4) reads 8 consecutive k of one row = one 16-byte
+// LDS read, no transposition anywhere.
+//
+// Tiling: 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile =
+// 4x4 MFMA 16x16x32 tiles.  The MFMA is issued "swapped" (W fragment as the A operand, the
+// activation fragment as B) so that each lane ends up with 4 CONSECUTIVE output columns of one
+// output row -> 8-byte bf16 / 16-byte fp32 vector epilogue accesses.
+//
+// LDS: 2 stages x (A 128x64 + W 128x64) bf16 = 64 KiB, XOR-swizzled in 16-byte chunks
+// (chunk ^= (row>>1)&7) so the ds_read_b128 lane groups of gfx950 are conflict-free.
+// Global->LDS goes through registers (16 B per lane, issued a full k-tile ahead of its use),
+// one barrier per k-tile.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+struct EpiArgs {
+  void* C;
+  int ldc;
+  // KV bank
+  bf16* bank_k;
+  bf16* bank_vt;
+  int S, H, B, inner;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                           int M, int N, int K, int lda, EpiArgs ep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int r16 = lane & 15, g = lane >> 4;
+
+  // staging map: 4 passes, thread -> (row = tid>>3 + 32*i, chunk = tid&7)
+  const int srow = tid >> 3, schunk = tid & 7;
+  const bf16* a_src[4];
+  const bf16* w_src[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = srow + 32 * i;
+    a_ok[i] = (m0 + row) < M;
+    a_src[i] = A + (size_t)(a_ok[i] ? (m0 + row) : 0) * lda + schunk * 8;
+    w_src[i] = W + (size_t)(n0 + row) * K + schunk * 8;
+  }
+  bf16x8 ra[4], rw[4];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = a_ok[i] ? ld_global_b128(a_src[i] + kt * BK) : zero_bf16x8();
+      rw[i] = ld_global_b128(w_src[i] + kt * BK);
+    }
+  };
+  auto store_tile = [&](int stage) {
+    char* sa = smem + stage * 2 * TILE_BYTES;
+    char* sw = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = srow + 32 * i;
+      *reinterpret_cast<bf16x8*>(sa + swz(row, schunk)) = ra[i];
+      *reinterpret_cast<bf16x8*>(sw + swz(row, schunk)) = rw[i];
+    }
+  };
+
+  f32x4 acc[4][4];  // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const char* sa = smem + stage * 2 * TILE_BYTES;
+    const char* sw = sa + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fw[4], fa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fw[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + r16, ks * 4 + g));
+        fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + r16, ks * 4 + g));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
+    }
+    if (kt + 1 < nkt) store_tile(stage ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][j] lane (r16,g) element e = C[m = m0+wm*64+j*16+r16][n = n0+wn*64+i*16+4g+e]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + r16;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = n0 + wn * 64 + i * 16 + 4 * g;
+      f32x4 v = acc[i][j];
+      if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
+        if constexpr (EPI == GRAM_EPI_BF16_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + n) = o;
+      } else if constexpr (EPI == GRAM_EPI_F32_ADD) {
+        f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n);
+        f32x4 old = *p;
+        *p = old + v;
+      } else if constexpr (EPI == GRAM_EPI_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n) = v;
+      } else {  // GRAM_EPI_KV_BANK
+        const int b = m / ep.S, s = m - b * ep.S;
+        const int lw = n / ep.inner;  // layer*2 + which   (uniform per block: inner % 128 == 0)
+        const int layer = lw >> 1, which = lw & 1;
+        const int rem = n - lw * ep.inner;
+        const int h = rem >> 6, d = rem & 63;
+        const size_t head = ((size_t)layer * ep.B + b) * ep.H + h;
+        if (which == 0) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x4*>(ep.bank_k + (head * ep.S + s) * 64 + d) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ep.bank_vt[(head * 64 + d + e) * ep.S + s] = (bf16)v[e];
+        }
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+  dim3 grid(N / BN, (M + BM - 1) / BM);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(256), 4 * TILE_BYTES, st, (const bf16*)A, (const bf16*)W, M, N, K,
+                     lda, ep);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int gram_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, int epilogue,
+                              const gram_kv_bank_t* bank, void* stream) {
+  if (M < 1 || N % BN != 0 || K % BK != 0 || lda < K || (lda & 7)) return GRAM_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  EpiArgs ep{};
+  ep.C = C;
+  ep.ldc = ldc;
+  switch (epilogue) {
+    case GRAM_EPI_BF16:
+      if (!C || (ldc & 3)) return GRAM_E_ARG;
+      return launch<GRAM_EPI_BF16>(A, W, M, N, K, lda, ep, st);
+    case GRAM_EPI_BF16_RELU:
+      if (!C || (ldc & 3)) return GRAM_E_ARG;
+      return launch<GRAM_EPI_BF16_RELU>(A, W, M, N, K, lda, ep, st);
+    case GRAM_EPI_F32_ADD:
+      if (!C || (ldc & 3)) return GRAM_E_ARG;
+      return launch<GRAM_EPI_F32_ADD>(A, W, M, N, K, lda, ep, st);
+    case GRAM_EPI_F32:
+      if (!C || (ldc & 3)) return GRAM_E_ARG;
+      return launch<GRAM_EPI_F32>(A, W, M, N, K, lda, ep, st);
+    case GRAM_EPI_KV_BANK: {
+      if (!bank || !bank->k || !bank->vt) return GRAM_E_ARG;
+      const int inner = bank->H * 64;
+      if (inner % BN != 0 || N != bank->n_layers * 2 * inner || M != bank->B * bank->S || bank->S % 16 != 0)
+        return GRAM_E_ARG;
+      ep.bank_k = (bf16*)bank->k;
+      ep.bank_vt = (bf16*)bank->vt;
+      ep.S = bank->S;
+      ep.H = bank->H;
+      ep.B = bank->B;
+      ep.inner = inner;
+      return launch<GRAM_EPI_KV_BANK>(A, W, M, N, K, lda, ep, st);
+    }
+    default:
+      return GRAM_E_ARG;
+  }
+}

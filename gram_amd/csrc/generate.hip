@@ -1,0 +1,284 @@
+// generate.hip -- host-side orchestration of the scoring path behind the C ABI: the model
+// handle, the workspace carve, and the encode -> fuse -> bank -> decode-loop launch sequences.
+// Nothing here allocates device memory or synchronises (except the optional 4-byte width read
+// at the end of gram_generate); every launch goes to the caller's stream, so the whole
+// generate() is one stream-ordered launch train.
+//
+// Reference call graph being replaced:
+//   GRAM.generate gram.py:74-107 -> EncoderWrapper.forward gram.py:200-256 -> T5Stack (encoder)
+//   gram_t5_modeling.py:1037-1296 -> HF beam_search -> per step
+//   T5ForConditionalGeneration_GRAM.forward gram_t5.py:118-287 -> T5Stack (decoder) -> lm_head.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "common.h"
+
+struct gram_model {
+  gram_model_desc_t d;
+  std::vector<const float*> enc_ln1, enc_ln2, dec_ln1, dec_ln2, dec_ln3;
+  std::vector<const void*> enc_wqkv, enc_wo, enc_wi, enc_wo2, dec_wqkv, dec_wo, dec_wq_x, dec_wo_x, dec_wi, dec_wo2;
+};
+
+namespace {
+
+struct Carve {
+  char* base;
+  int64_t off;
+  explicit Carve(void* p) : base((char*)p), off(0) {}
+  template <typename T>
+  T* take(int64_t n) {
+    off = (off + 255) & ~(int64_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * (int64_t)sizeof(T);
+    return p;
+  }
+};
+
+struct Workspace {
+  // encoder
+  float* x;         // [Me][d]   residual stream (fp32)
+  bf16* h;          // [Me][d]   normed activations (GEMM A operand)
+  bf16* qkv;        // [Me][3*inner]
+  bf16* attn;       // [Me][inner]
+  bf16* u;          // [Me][d_ff]
+  // fused bank
+  bf16* bank_k;     // [layers][B][H][S][64]
+  bf16* bank_vt;    // [layers][B][H][64][S]
+  // decoder
+  float* xd;        // [R][d]
+  bf16* hd;         // [R][d]
+  bf16* qkvd;       // [R][3*inner]
+  bf16* attnd;      // [R][inner]
+  bf16* qx;         // [R][inner]
+  bf16* ud;         // [R][d_ff]
+  bf16* kcache;     // [layers][Tmax][R][inner]
+  bf16* vcache;
+  float* logits;    // [R][V]
+  float* lse;       // [R]
+  // beam state
+  gram_beam_state_t beam;
+  int32_t* width;
+  int64_t bytes;
+};
+
+Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int Tmax) {
+  const gram_model_desc_t& c = m->d;
+  const int64_t d = c.d_model, inner = (int64_t)c.n_heads * 64, F = c.d_ff, V = c.vocab;
+  const int64_t Me = (int64_t)B * N * L, S = (int64_t)N * L, R = (int64_t)B * K, nl = c.n_dec_layers;
+  Carve cv(ws);
+  Workspace w{};
+  w.x = cv.take<float>(Me * d);
+  w.h = cv.take<bf16>(Me * d);
+  w.qkv = cv.take<bf16>(Me * 3 * inner);
+  w.attn = cv.take<bf16>(Me * inner);
+  w.u = cv.take<bf16>(Me * F);
+  w.bank_k = cv.take<bf16>(nl * B * c.n_heads * S * 64);
+  w.bank_vt = cv.take<bf16>(nl * B * c.n_heads * S * 64);
+  w.xd = cv.take<float>(R * d);
+  w.hd = cv.take<bf16>(R * d);
+  w.qkvd = cv.take<bf16>(R * 3 * inner);
+  w.attnd = cv.take<bf16>(R * inner);
+  w.qx = cv.take<bf16>(R * inner);
+  w.ud = cv.take<bf16>(R * F);
+  w.kcache = cv.take<bf16>(nl * Tmax * R * inner);
+  w.vcache = cv.take<bf16>(nl * Tmax * R * inner);
+  w.logits = cv.take<float>(R * V);
+  w.lse = cv.take<float>(R);
+  gram_beam_state_t& s = w.beam;
+  s.B = B;
+  s.K = K;
+  s.Tmax = Tmax;
+  s.length_penalty = 1.f;
+  s.eos = 1;
+  s.pad = 0;
+  s.tokens = cv.take<int32_t>(R);
+  s.node = cv.take<int32_t>(R);
+  s.beam_scores = cv.take<float>(R);
+  s.seq = cv.take<int32_t>(R * Tmax);
+  s.anc = cv.take<int32_t>((int64_t)Tmax * R);
+  s.done = cv.take<int32_t>(B);
+  s.n_hyps = cv.take<int32_t>(B);
+  s.hyp_score = cv.take<double>((int64_t)B * (K + 1));
+  s.worst = cv.take<double>(B);
+  s.hyp_len = cv.take<int32_t>((int64_t)B * (K + 1));
+  s.hyp_tok = cv.take<int32_t>((int64_t)B * (K + 1) * Tmax);
+  s.error = cv.take<int32_t>(4);
+  w.width = cv.take<int32_t>(4);
+  w.bytes = (cv.off + 255) & ~(int64_t)255;
+  return w;
+}
+
+int check_shapes(const gram_model* m, int B, int N, int L, int K, int Tmax) {
+  if (!m || B < 1 || N < 1 || N > m->d.max_passages || L < 32 || L > GRAM_MAX_PASSAGE_LEN || (L & 31) || K < 1 ||
+      K > GRAM_MAX_BEAMS || Tmax < 2 || Tmax > GRAM_MAX_DEC_LEN)
+    return GRAM_E_ARG;
+  return 0;
+}
+
+#define TRY(x)            \
+  do {                    \
+    int e__ = (x);        \
+    if (e__) return e__;  \
+  } while (0)
+
+int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const uint8_t* mask, int B, int N, int L, void* st) {
+  const gram_model_desc_t& c = m->d;
+  const int d = c.d_model, inner = c.n_heads * 64, F = c.d_ff, H = c.n_heads;
+  const int Me = B * N * L, P = B * N;
+  TRY(gram_embed_i64(c.embed_f32, ids, w.x, Me, d, st));
+  for (int i = 0; i < c.n_enc_layers; ++i) {
+    TRY(gram_rmsnorm_bf16(w.x, m->enc_ln1[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, st));
+    TRY(gram_gemm_bf16(w.h, m->enc_wqkv[i], w.qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, st));
+    TRY(gram_enc_self_attn(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, st));
+    TRY(gram_gemm_bf16(w.attn, m->enc_wo[i], w.x, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, st));
+    TRY(gram_rmsnorm_bf16(w.x, m->enc_ln2[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, st));
+    TRY(gram_gemm_bf16(w.h, m->enc_wi[i], w.u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, st));
+    TRY(gram_gemm_bf16(w.u, m->enc_wo2[i], w.x, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, st));
+  }
+  // final norm + per-passage position embedding = the late fusion (gram.py:238-255); the
+  // (B*N, L, d) -> (B, N*L, d) view is free: rows are already user-major.
+  TRY(gram_rmsnorm_bf16(w.x, c.enc_final_ln, w.h, Me, d, c.eps, 1.f, c.use_position_embedding ? c.pos_emb_f32 : nullptr, N, L,
+                        st));
+  // every decoder layer's cross K/V in ONE GEMM, scattered into the beam-shared bank
+  gram_kv_bank_t bank{w.bank_k, w.bank_vt, c.n_dec_layers, B, H, N * L};
+  TRY(gram_gemm_bf16(w.h, c.dec_wkv_x_all, nullptr, Me, c.n_dec_layers * 2 * inner, d, d, 0, GRAM_EPI_KV_BANK, &bank, st));
+  return 0;
+}
+
+int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, const int32_t* anc, const uint8_t* mask, int B,
+                int N, int L, int K, int Tmax, int t, float* logits, void* st) {
+  const gram_model_desc_t& c = m->d;
+  const int d = c.d_model, inner = c.n_heads * 64, F = c.d_ff, H = c.n_heads, V = c.vocab;
+  const int R = B * K, S = N * L;
+  const size_t bank_layer = (size_t)B * H * S * 64;
+  const size_t cache_layer = (size_t)Tmax * R * inner;
+  TRY(gram_embed_i32(c.embed_f32, tokens, w.xd, R, d, st));
+  for (int i = 0; i < c.n_dec_layers; ++i) {
+    TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln1[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
+    TRY(gram_gemm_bf16(w.hd, m->dec_wqkv[i], w.qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, st));
+    TRY(gram_dec_self_attn(w.qkvd, w.kcache + i * cache_layer, w.vcache + i * cache_layer, anc, c.dec_bias_f32, w.attnd, R, H, t,
+                           Tmax, st));
+    TRY(gram_gemm_bf16(w.attnd, m->dec_wo[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, st));
+    TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln2[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
+    TRY(gram_gemm_bf16(w.hd, m->dec_wq_x[i], w.qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, st));
+    TRY(gram_cross_attn_decode(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd, B, K, H, S, st));
+    TRY(gram_gemm_bf16(w.attnd, m->dec_wo_x[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, st));
+    TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln3[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
+    TRY(gram_gemm_bf16(w.hd, m->dec_wi[i], w.ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, st));
+    TRY(gram_gemm_bf16(w.ud, m->dec_wo2[i], w.xd, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, st));
+  }
+  const float scale = c.tie_word_embeddings ? 1.0f / sqrtf((float)d) : 1.f;  // gram_t5.py:249-252
+  TRY(gram_rmsnorm_bf16(w.xd, c.dec_final_ln, w.hd, R, d, c.eps, scale, nullptr, 1, 1, st));
+  TRY(gram_gemm_bf16(w.hd, c.lm_head_bf16, logits, R, V, d, d, V, GRAM_EPI_F32, nullptr, st));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int gram_abi_version(void) { return GRAM_ABI_VERSION; }
+
+extern "C" gram_model_t* gram_model_create(const gram_model_desc_t* d) {
+  if (!d || d->vocab % 128 || d->d_model % 128 || d->d_ff % 128 || d->n_heads < 1 || d->n_heads > 16 ||
+      (d->n_heads * 64) % 128 || d->d_model > 1024 || d->n_enc_layers < 1 || d->n_dec_layers < 1)
+    return nullptr;
+  gram_model* m = new gram_model();
+  m->d = *d;
+  auto cpf = [](std::vector<const float*>& v, const float* const* src, int n) { v.assign(src, src + n); };
+  auto cpv = [](std::vector<const void*>& v, const void* const* src, int n) { v.assign(src, src + n); };
+  cpf(m->enc_ln1, d->enc_ln1, d->n_enc_layers);
+  cpf(m->enc_ln2, d->enc_ln2, d->n_enc_layers);
+  cpv(m->enc_wqkv, d->enc_wqkv, d->n_enc_layers);
+  cpv(m->enc_wo, d->enc_wo, d->n_enc_layers);
+  cpv(m->enc_wi, d->enc_wi, d->n_enc_layers);
+  cpv(m->enc_wo2, d->enc_wo2, d->n_enc_layers);
+  cpf(m->dec_ln1, d->dec_ln1, d->n_dec_layers);
+  cpf(m->dec_ln2, d->dec_ln2, d->n_dec_layers);
+  cpf(m->dec_ln3, d->dec_ln3, d->n_dec_layers);
+  cpv(m->dec_wqkv, d->dec_wqkv, d->n_dec_layers);
+  cpv(m->dec_wo, d->dec_wo, d->n_dec_layers);
+  cpv(m->dec_wq_x, d->dec_wq_x, d->n_dec_layers);
+  cpv(m->dec_wo_x, d->dec_wo_x, d->n_dec_layers);
+  cpv(m->dec_wi, d->dec_wi, d->n_dec_layers);
+  cpv(m->dec_wo2, d->dec_wo2, d->n_dec_layers);
+  // the descriptor's per-layer arrays now point at storage the handle owns
+  m->d.enc_ln1 = m->enc_ln1.data();
+  m->d.enc_ln2 = m->enc_ln2.data();
+  m->d.enc_wqkv = m->enc_wqkv.data();
+  m->d.enc_wo = m->enc_wo.data();
+  m->d.enc_wi = m->enc_wi.data();
+  m->d.enc_wo2 = m->enc_wo2.data();
+  m->d.dec_ln1 = m->dec_ln1.data();
+  m->d.dec_ln2 = m->dec_ln2.data();
+  m->d.dec_ln3 = m->dec_ln3.data();
+  m->d.dec_wqkv = m->dec_wqkv.data();
+  m->d.dec_wo = m->dec_wo.data();
+  m->d.dec_wq_x = m->dec_wq_x.data();
+  m->d.dec_wo_x = m->dec_wo_x.data();
+  m->d.dec_wi = m->dec_wi.data();
+  m->d.dec_wo2 = m->dec_wo2.data();
+  return m;
+}
+
+extern "C" void gram_model_destroy(gram_model_t* m) { delete m; }
+
+extern "C" int64_t gram_workspace_bytes(const gram_model_t* m, int B, int N, int L, int K, int max_length) {
+  if (check_shapes(m, B, N, L, K, max_length)) return GRAM_E_ARG;
+  return carve(m, nullptr, B, N, L, K, max_length).bytes;
+}
+
+extern "C" int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L,
+                                 void* workspace, int64_t workspace_bytes, int K, int max_length, void* enc_out_bf16,
+                                 void* stream) {
+  TRY(check_shapes(m, B, N, L, K, max_length));
+  Workspace w = carve(m, workspace, B, N, L, K, max_length);
+  if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
+  TRY(encode(m, w, input_ids, mask, B, N, L, stream));
+  if (enc_out_bf16) {
+    hipError_t e = hipMemcpyAsync(enc_out_bf16, w.h, (size_t)B * N * L * m->d.d_model * sizeof(bf16), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+extern "C" int gram_decode_step(const gram_model_t* m, const int32_t* tokens, const int32_t* anc, const uint8_t* mask, int B, int N,
+                                int L, int K, int max_length, int t, void* workspace, int64_t workspace_bytes, float* logits,
+                                void* stream) {
+  TRY(check_shapes(m, B, N, L, K, max_length));
+  if (t < 0 || t >= max_length - 1 || !logits) return GRAM_E_ARG;
+  Workspace w = carve(m, workspace, B, N, L, K, max_length);
+  if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
+  return decode_step(m, w, tokens, anc, mask, B, N, L, K, max_length, t, logits, stream);
+}
+
+extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K,
+                             int nret, int max_length, float length_penalty, const gram_trie_t* trie, void* workspace,
+                             int64_t workspace_bytes, int64_t* sequences, float* scores, int32_t* width_host, void* stream) {
+  TRY(check_shapes(m, B, N, L, K, max_length));
+  if (!trie || nret < 1 || nret > K || !sequences || !scores) return GRAM_E_ARG;
+  if ((long long)K * trie->max_fanout > 16384) return GRAM_E_ARG;
+  Workspace w = carve(m, workspace, B, N, L, K, max_length);
+  if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
+  w.beam.length_penalty = length_penalty;
+  TRY(encode(m, w, input_ids, mask, B, N, L, stream));
+  TRY(gram_beam_init(&w.beam, trie, /*decoder_start_token_id=*/0, stream));
+  // fixed max_length-1 steps: finished users are padded exactly as BeamSearchScorer.process
+  // pads them, so skipping HF's all-done early exit changes nothing and needs no host sync
+  for (int t = 0; t + 1 < max_length; ++t) {
+    TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, K, max_length, t, w.logits, stream));
+    TRY(gram_row_lse(w.logits, w.lse, B * K, m->d.vocab, stream));
+    TRY(gram_beam_step(&w.beam, trie, w.logits, w.lse, m->d.vocab, t + 1, stream));
+  }
+  TRY(gram_beam_finalize(&w.beam, nret, max_length, sequences, scores, w.width, stream));
+  if (width_host) {
+    int32_t host[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(&host[0], w.width, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&host[1], w.beam.error, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    *width_host = host[0];
+    if (host[1] != 0) return GRAM_E_BEAM;
+  }
+  return 0;
+}

@@ -1,0 +1,118 @@
+// rowops.hip -- HBM-bound row kernels: embedding gather, T5 RMSNorm (+late-fusion position
+// embedding / lm_head rescale fused), row log-sum-exp.  One wave per row, 16-byte accesses.
+#include "common.h"
+
+namespace {
+
+template <typename IdT>
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ table, const IdT* __restrict__ ids,
+                                                    float* __restrict__ x, int rows, int d) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const f32x4* src = reinterpret_cast<const f32x4*>(table + (size_t)ids[row] * d);
+  f32x4* dst = reinterpret_cast<f32x4*>(x + (size_t)row * d);
+  for (int i = lane; i < d / 4; i += 64) dst[i] = src[i];
+}
+
+// T5LayerNorm (gram_t5_modeling.py:262-276): fp32 variance, no mean subtraction, no bias.
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      bf16* __restrict__ out, int rows, int d, float eps, float scale,
+                                                      const float* __restrict__ pos, int N, int L) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * d);
+  const int nv = d / 4;
+  f32x4 v[4];  // d <= 1024
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    int i = lane + it * 64;
+    if (i < nv) {
+      v[it] = xr[i];
+      ss += v[it][0] * v[it][0] + v[it][1] * v[it][1] + v[it][2] * v[it][2] + v[it][3] * v[it][3];
+    }
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)d + eps);
+  const f32x4* wr = reinterpret_cast<const f32x4*>(w);
+  const f32x4* pr = pos ? reinterpret_cast<const f32x4*>(pos + (size_t)((row / L) % N) * d) : nullptr;
+  bf16x4* o = reinterpret_cast<bf16x4*>(out + (size_t)row * d);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    int i = lane + it * 64;
+    if (i < nv) {
+      f32x4 g = wr[i];
+      f32x4 p = pr ? pr[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = (bf16)(g[e] * (v[it][e] * rs) * scale + p[e]);
+      o[i] = r;
+    }
+  }
+}
+
+// lse[r] = log sum_v exp(logits[r][v]); one block per row, online (max,sum) per thread.
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ logits, float* __restrict__ lse, int V) {
+  __shared__ float sm[4], ss[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const f32x4* p = reinterpret_cast<const f32x4*>(logits + (size_t)row * V);
+  float m = -INFINITY, s = 0.f;
+  for (int i = tid; i < V / 4; i += 256) {
+    f32x4 v = p[i];
+    float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    if (vm > m) {
+      s *= __expf(m - vm);
+      m = vm;
+    }
+    s += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
+  }
+  float wm = wave_max(m);
+  s *= (m == -INFINITY) ? 0.f : __expf(m - wm);
+  s = wave_sum(s);
+  if ((tid & 63) == 0) {
+    sm[tid >> 6] = wm;
+    ss[tid >> 6] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float S = 0.f;
+    for (int i = 0; i < 4; ++i) S += (sm[i] == -INFINITY) ? 0.f : ss[i] * __expf(sm[i] - M);
+    lse[row] = M + logf(S);
+  }
+}
+
+}  // namespace
+
+extern "C" int gram_embed_i64(const float* table, const int64_t* ids, float* x, int rows, int d, void* stream) {
+  if (rows < 1 || (d & 3)) return GRAM_E_ARG;
+  hipLaunchKernelGGL(embed_kernel<int64_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, x, rows, d);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int gram_embed_i32(const float* table, const int32_t* ids, float* x, int rows, int d, void* stream) {
+  if (rows < 1 || (d & 3)) return GRAM_E_ARG;
+  hipLaunchKernelGGL(embed_kernel<int32_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, x, rows, d);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int gram_rmsnorm_bf16(const float* x, const float* w, void* out, int rows, int d, float eps, float scale,
+                                 const float* pos, int N, int L, void* stream) {
+  if (rows < 1 || (d & 3) || d > 1024 || (pos && (N < 1 || L < 1))) return GRAM_E_ARG;
+  if (!pos) {
+    N = 1;
+    L = 1;
+  }
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)out, rows, d, eps,
+                     scale, pos, N, L);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int gram_row_lse(const float* logits, float* lse, int R, int V, void* stream) {
+  if (R < 1 || (V & 3)) return GRAM_E_ARG;
+  hipLaunchKernelGGL(row_lse_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, lse, V);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,372 @@
+"""GRAM model wrapper: the reference's ``src/model/gram.py`` interface over libgram_hip.so.
+
+Same constructor (``GRAM(config)``), same state-dict key layout, same
+``load_t5`` / ``load_state_dict`` / ``generate`` signatures as the reference class
+(gram.py:14-107,162-165), so ``main_generative_gram.py`` and the runners drive it unchanged.
+``generate`` runs entirely on the MI355X through ONE C-ABI call (``gram_generate``): encoder,
+late fusion, the beam-shared KV bank, and the Trie-constrained beam search all stay on the
+device; there is no PyTorch-op or CPU fallback.
+
+Out of scope here (training half): ``forward`` with labels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, Optional
+
+import torch
+from torch import nn
+
+from .. import _lib
+from ..utils.generation_trie import FlatTrie, Trie
+
+
+class GenerateOutput(dict):
+    """Mapping with attribute access, standing in for HF's BeamSearchEncoderDecoderOutput:
+    the runner reads ``prediction["sequences"]`` / ``prediction["sequences_scores"]``
+    (single_runner_gram.py:654-655)."""
+
+    __getattr__ = dict.get
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted parameter names."""
+
+
+def _register(root: nn.Module, dotted: str, param: nn.Parameter) -> None:
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        child = mod._modules.get(p)
+        if child is None:
+            child = _Node()
+            mod.add_module(p, child)
+        mod = child
+    mod.register_parameter(parts[-1], param)
+
+
+def relative_position_bucket(rel: torch.Tensor, bidirectional: bool, num_buckets: int, max_distance: int) -> torch.Tensor:
+    """Bucket index of a relative position (key - query).  Same integer results as
+    T5Attention._relative_position_bucket (gram_t5_modeling.py:398-450), evaluated once on the
+    host to build the per-head bias tables the kernels index."""
+    rel = rel.to(torch.long)
+    out = torch.zeros_like(rel)
+    n = num_buckets
+    if bidirectional:
+        n //= 2
+        out += (rel > 0).long() * n
+        dist = rel.abs()
+    else:
+        dist = (-rel).clamp(min=0)
+    exact = n // 2
+    log_part = exact + (torch.log(dist.float() / exact) / math.log(max_distance / exact) * (n - exact)).long()
+    log_part = log_part.clamp(max=n - 1)
+    return out + torch.where(dist < exact, dist, log_part)
+
+
+class GRAM(nn.Module):
+    main_input_name = "input_ids"
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        c = config
+        if c.d_kv != 64:
+            raise ValueError("gram_amd kernels are built for d_kv == 64 (every T5 checkpoint the reference uses)")
+        if getattr(c, "feed_forward_proj", "relu") not in ("relu",):
+            raise ValueError("only the ReLU feed-forward of t5-{small,base,large} is on the path")
+        self.max_seq_len = getattr(c, "max_seq_len", 128)
+        self.max_item_num = getattr(c, "max_item_num", 20)
+        self.use_position_embedding = bool(getattr(c, "use_position_embedding", True))
+        d, inner, F, V = c.d_model, c.num_heads * c.d_kv, c.d_ff, c.vocab_size
+        self.model_dim = d
+        dec_layers = c.num_decoder_layers if getattr(c, "num_decoder_layers", None) is not None else c.num_layers
+        self._n_enc, self._n_dec = c.num_layers, dec_layers
+
+        def P(*shape):
+            return nn.Parameter(torch.empty(*shape, dtype=torch.float32))
+
+        shared = P(V, d)
+        _register(self, "shared.weight", shared)
+        _register(self, "encoder.encoder.embed_tokens.weight", shared)
+        _register(self, "decoder.embed_tokens.weight", shared)
+
+        def attn(prefix, rel):
+            _register(self, prefix + ".q.weight", P(inner, d))
+            _register(self, prefix + ".k.weight", P(inner, d))
+            _register(self, prefix + ".v.weight", P(inner, d))
+            _register(self, prefix + ".o.weight", P(d, inner))
+            if rel:
+                _register(self, prefix + ".relative_attention_bias.weight", P(c.relative_attention_num_buckets, c.num_heads))
+
+        def ff(prefix):
+            _register(self, prefix + ".DenseReluDense.wi.weight", P(F, d))
+            _register(self, prefix + ".DenseReluDense.wo.weight", P(d, F))
+
+        for i in range(self._n_enc):
+            p = f"encoder.encoder.block.{i}.module.layer"
+            attn(p + ".0.SelfAttention", i == 0)
+            _register(self, p + ".0.layer_norm.weight", P(d))
+            ff(p + ".1")
+            _register(self, p + ".1.layer_norm.weight", P(d))
+        _register(self, "encoder.encoder.final_layer_norm.weight", P(d))
+        for i in range(self._n_dec):
+            p = f"decoder.block.{i}.layer"
+            attn(p + ".0.SelfAttention", i == 0)
+            _register(self, p + ".0.layer_norm.weight", P(d))
+            attn(p + ".1.EncDecAttention", False)
+            _register(self, p + ".1.layer_norm.weight", P(d))
+            ff(p + ".2")
+            _register(self, p + ".2.layer_norm.weight", P(d))
+        _register(self, "decoder.final_layer_norm.weight", P(d))
+        if self.use_position_embedding:
+            pos = P(self.max_item_num + 1, d)  # one extra for the coarse user prompt (gram.py:23-26)
+            _register(self, "position_embedding.weight", pos)
+            _register(self, "encoder.position_embedding.weight", pos)
+        _register(self, "lm_head.weight", shared if getattr(c, "tie_word_embeddings", True) else P(V, d))
+        self._init_weights()
+        self._packed = None  # (device, version, handle, keepalive)
+        self._version = 0
+        self._workspace = None
+        self._tries: Dict[int, FlatTrie] = {}
+
+    # ------------------------------------------------------------------ weights
+    def _init_weights(self) -> None:
+        """Distributions of the reference initialiser (gram_t5_modeling.py:865-929, gram.py:32-33)."""
+        c = self.config
+        d, dk, H, F = c.d_model, c.d_kv, c.num_heads, c.d_ff
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("layer_norm.weight"):
+                    p.fill_(1.0)
+                elif name.endswith(".q.weight"):
+                    p.normal_(0.0, (d * dk) ** -0.5)
+                elif name.endswith((".k.weight", ".v.weight", "wi.weight", "relative_attention_bias.weight")):
+                    p.normal_(0.0, d ** -0.5)
+                elif name.endswith(".o.weight"):
+                    p.normal_(0.0, (H * dk) ** -0.5)
+                elif name.endswith("wo.weight"):
+                    p.normal_(0.0, F ** -0.5)
+                elif name.endswith("position_embedding.weight"):
+                    p.normal_(0.0, 0.02)
+                else:
+                    p.normal_(0.0, 1.0)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._invalidate()
+        return out
+
+    def load_t5(self, state_dict):
+        """gram.py:162-165: load a plain T5 checkpoint (encoder blocks are not wrapped there:
+        ``encoder.block.{i}.layer...``), non-strict, leaving ``position_embedding`` as initialised."""
+        remapped = {}
+        for k, v in state_dict.items():
+            if k.startswith("encoder.block."):
+                parts = k.split(".")
+                k = "encoder.encoder.block." + parts[2] + ".module." + ".".join(parts[3:])
+            elif k.startswith("encoder.") and not k.startswith("encoder.encoder."):
+                k = "encoder." + k
+            remapped[k] = v
+        return self.load_state_dict(remapped, strict=False)
+
+    def _invalidate(self) -> None:
+        self._version += 1
+
+    def _apply(self, fn, *a, **kw):  # .to()/.cuda()/.float() all funnel through here
+        out = super()._apply(fn, *a, **kw)
+        self._invalidate()
+        return out
+
+    def train(self, mode: bool = True):
+        # parameters may have been updated by an optimizer while training: repack on leaving train mode
+        if self.training != bool(mode):
+            self._invalidate()
+        return super().train(mode)
+
+    def wrap_encoder(self, use_checkpoint=False):  # API no-ops kept for drop-in compatibility
+        pass
+
+    def unwrap_encoder(self):
+        pass
+
+    def set_checkpoint(self, use_checkpoint):
+        pass
+
+    def forward(self, input_ids=None, attention_mask=None, **kwargs):
+        raise NotImplementedError(
+            "gram_amd implements the generative *scoring* path (GRAM.generate). The teacher-forced training "
+            "forward/backward (SURVEY.md §8f N4) is out of scope of this build."
+        )
+
+    # ------------------------------------------------------------------ device packing
+    def _device(self) -> torch.device:
+        return self.get_parameter("shared.weight").device
+
+    def _pack(self):
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError(
+                "gram_amd.GRAM.generate needs the model on a ROCm device (model.to('cuda')); there is no CPU path"
+            )
+        if self._packed is not None and self._packed[0] == dev and self._packed[1] == self._version:
+            return self._packed[2]
+        lib = _lib.load()
+        if self._packed is not None:
+            lib.gram_model_destroy(self._packed[2])
+            self._packed = None
+        c = self.config
+        H = c.num_heads
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        keep = []
+
+        def f32(t):
+            t = t.to(dev, torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def b16(t):
+            t = t.to(dev, torch.float32).to(torch.bfloat16).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def ptr_array(vals):
+            arr = (C.c_void_p * len(vals))(*vals)
+            keep.append(arr)
+            return C.cast(arr, C.POINTER(C.c_void_p))
+
+        def qkv(prefix):
+            return b16(torch.cat([sd[prefix + ".q.weight"], sd[prefix + ".k.weight"], sd[prefix + ".v.weight"]], 0))
+
+        # relative-bias tables: encoder [H][255] by (key - query + 127), decoder [H][32] by distance
+        nb, md = c.relative_attention_num_buckets, c.relative_attention_max_distance
+        rel = torch.arange(-127, 128)
+        enc_tab = sd["encoder.encoder.block.0.module.layer.0.SelfAttention.relative_attention_bias.weight"].cpu().float()
+        enc_bias = enc_tab[relative_position_bucket(rel, True, nb, md)].t().contiguous()  # (H,255)
+        dist = torch.arange(0, _lib.GRAM_MAX_DEC_LEN)
+        dec_tab = sd["decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].cpu().float()
+        dec_bias = dec_tab[relative_position_bucket(-dist, False, nb, md)].t().contiguous()  # (H,32)
+
+        e = "encoder.encoder.block.{}.module.layer"
+        dd = "decoder.block.{}.layer"
+        ne, nd = self._n_enc, self._n_dec
+        wkv_all = torch.cat(
+            [torch.cat([sd[dd.format(i) + ".1.EncDecAttention.k.weight"], sd[dd.format(i) + ".1.EncDecAttention.v.weight"]], 0)
+             for i in range(nd)], 0)
+        desc = _lib.ModelDesc(
+            vocab=c.vocab_size, d_model=c.d_model, d_ff=c.d_ff, n_heads=H, n_enc_layers=ne, n_dec_layers=nd,
+            max_passages=self.max_item_num + 1, tie_word_embeddings=int(bool(getattr(c, "tie_word_embeddings", True))),
+            use_position_embedding=int(self.use_position_embedding), eps=float(c.layer_norm_epsilon),
+            embed_f32=f32(sd["shared.weight"]), lm_head_bf16=b16(sd["lm_head.weight"]),
+            pos_emb_f32=f32(sd["position_embedding.weight"]) if self.use_position_embedding else None,
+            enc_bias_f32=f32(enc_bias), dec_bias_f32=f32(dec_bias),
+            enc_final_ln=f32(sd["encoder.encoder.final_layer_norm.weight"]),
+            dec_final_ln=f32(sd["decoder.final_layer_norm.weight"]),
+            enc_ln1=ptr_array([f32(sd[e.format(i) + ".0.layer_norm.weight"]) for i in range(ne)]),
+            enc_wqkv=ptr_array([qkv(e.format(i) + ".0.SelfAttention") for i in range(ne)]),
+            enc_wo=ptr_array([b16(sd[e.format(i) + ".0.SelfAttention.o.weight"]) for i in range(ne)]),
+            enc_ln2=ptr_array([f32(sd[e.format(i) + ".1.layer_norm.weight"]) for i in range(ne)]),
+            enc_wi=ptr_array([b16(sd[e.format(i) + ".1.DenseReluDense.wi.weight"]) for i in range(ne)]),
+            enc_wo2=ptr_array([b16(sd[e.format(i) + ".1.DenseReluDense.wo.weight"]) for i in range(ne)]),
+            dec_ln1=ptr_array([f32(sd[dd.format(i) + ".0.layer_norm.weight"]) for i in range(nd)]),
+            dec_wqkv=ptr_array([qkv(dd.format(i) + ".0.SelfAttention") for i in range(nd)]),
+            dec_wo=ptr_array([b16(sd[dd.format(i) + ".0.SelfAttention.o.weight"]) for i in range(nd)]),
+            dec_ln2=ptr_array([f32(sd[dd.format(i) + ".1.layer_norm.weight"]) for i in range(nd)]),
+            dec_wq_x=ptr_array([b16(sd[dd.format(i) + ".1.EncDecAttention.q.weight"]) for i in range(nd)]),
+            dec_wo_x=ptr_array([b16(sd[dd.format(i) + ".1.EncDecAttention.o.weight"]) for i in range(nd)]),
+            dec_ln3=ptr_array([f32(sd[dd.format(i) + ".2.layer_norm.weight"]) for i in range(nd)]),
+            dec_wi=ptr_array([b16(sd[dd.format(i) + ".2.DenseReluDense.wi.weight"]) for i in range(nd)]),
+            dec_wo2=ptr_array([b16(sd[dd.format(i) + ".2.DenseReluDense.wo.weight"]) for i in range(nd)]),
+            dec_wkv_x_all=b16(wkv_all),
+        )
+        handle = lib.gram_model_create(C.byref(desc))
+        if not handle:
+            raise _lib.GramHipError("gram_model_create rejected the configuration (dims must be multiples of 128, heads <= 16)")
+        self._packed = (dev, self._version, handle, keep)
+        return handle
+
+    def _get_workspace(self, handle, B, N, L, K, max_length) -> torch.Tensor:
+        lib = _lib.load()
+        need = lib.gram_workspace_bytes(handle, B, N, L, K, max_length)
+        if need < 0:
+            raise _lib.GramHipError(
+                f"unsupported problem size B={B} N={N} L={L} K={K} max_length={max_length} "
+                f"(N <= max_item_num+1, L <= 128, K <= 64, max_length <= 32)"
+            )
+        dev = self._device()
+        if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        return self._workspace
+
+    def _flat_trie(self, fn: Callable) -> FlatTrie:
+        trie = None
+        for cell in getattr(fn, "__closure__", None) or ():
+            obj = cell.cell_contents
+            if hasattr(obj, "trie_dict") and hasattr(obj, "get"):
+                trie = obj
+                break
+        if trie is None:
+            raise NotImplementedError(
+                "prefix_allowed_tokens_fn must be the closure returned by "
+                "utils.generation_trie.prefix_allowed_tokens_fn(trie) (the only form the GRAM runners pass); "
+                "arbitrary Python callbacks would need one host round trip per beam per step"
+            )
+        key = id(trie)
+        cached = self._tries.get(key)
+        if cached is None or cached.n_sequences != len(trie):
+            cached = FlatTrie(trie)
+            self._tries = {key: cached}  # one live Trie per eval; drop stale ones
+        return cached
+
+    # ------------------------------------------------------------------ the hot path
+    @torch.no_grad()
+    def generate(self, input_ids, attention_mask, max_length, prefix_allowed_tokens_fn=None, num_beams=1,
+                 num_return_sequences=None, output_scores=True, return_dict_in_generate=True, length_penalty=1.0,
+                 **unused):
+        """GRAM.generate (gram.py:74-107) with the kwargs single_runner_gram.py:641-651 passes.
+
+        input_ids (B,N,L) int64, attention_mask (B,N,L) bool on the model's device.  Returns a
+        mapping with ``sequences`` (B*num_return_sequences, T) int64 -- user-major, best first,
+        0-padded, starting with the decoder start token -- and ``sequences_scores`` (fp32)."""
+        if prefix_allowed_tokens_fn is None:
+            raise NotImplementedError("unconstrained generation is not on GRAM's scoring path (a Trie is always passed)")
+        if input_ids.dim() != 3:
+            raise ValueError("input_ids must be (B, N, L)")
+        handle = self._pack()
+        lib = _lib.load()
+        dev = self._device()
+        K = int(num_beams)
+        nret = int(num_return_sequences or K)
+        B, N, L = input_ids.shape
+        ids = input_ids.to(dev, torch.int64)
+        mask = attention_mask.to(dev).ne(0).view(torch.uint8) if attention_mask.dtype != torch.bool else attention_mask.to(dev).view(torch.uint8)
+        Lp = (L + 31) // 32 * 32  # masked padding is invisible to attention: pad L to the kernel tile
+        if Lp != L:
+            ids = torch.nn.functional.pad(ids, (0, Lp - L))
+            mask = torch.nn.functional.pad(mask, (0, Lp - L))
+        ids, mask = ids.contiguous(), mask.contiguous()
+        flat = self._flat_trie(prefix_allowed_tokens_fn)
+        ctrie, _keep = flat.to_device(dev)
+        ws = self._get_workspace(handle, B, N, Lp, K, int(max_length))
+        seqs = torch.empty(B * nret, int(max_length), dtype=torch.int64, device=dev)
+        scores = torch.empty(B * nret, dtype=torch.float32, device=dev)
+        width = C.c_int32(0)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            rc = lib.gram_generate(handle, ids.data_ptr(), mask.data_ptr(), B, N, Lp, K, nret, int(max_length),
+                                   float(length_penalty), C.byref(ctrie), ws.data_ptr(), ws.numel(), seqs.data_ptr(),
+                                   scores.data_ptr(), C.byref(width), stream)
+        _lib.check(rc, "gram_generate")
+        seqs = seqs[:, : width.value]
+        if not return_dict_in_generate:
+            return seqs
+        return GenerateOutput(sequences=seqs, sequences_scores=scores)
+
+    def __del__(self):
+        try:
+            if self._packed is not None:
+                _lib.load().gram_model_destroy(self._packed[2])
+        except Exception:
+            pass

@@ -1,0 +1,222 @@
+/*
+ * gram_hip.h -- C ABI of libgram_hip.so: GRAM's multi-granular late-fusion generative scoring
+ * path on MI355X (gfx950), hand-written HIP kernels.
+ *
+ * The reference (zhaodong-liu/GRAM) is pure Python and has no FFI; its seam for this path is
+ *   src/model/gram.py:74-107        GRAM.generate(input_ids, attention_mask, max_length, **hf_kwargs)
+ *   src/runner/single_runner_gram.py:641-651   the call site (beam=K, top-K, Trie closure)
+ * Each entry point below names the reference function(s) it replaces.  INTEGRATION.md shows the
+ * ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, nothing allocates,
+ *     nothing synchronises (except gram_generate's final 4-byte width read when asked)
+ *   - bf16 = 16-bit brain float, row-major; "inner" = n_heads * 64; d_kv must be 64
+ *   - return value: 0 on success, >0 a hipError_t, <0 an argument error (GRAM_E_*)
+ */
+#ifndef GRAM_HIP_H
+#define GRAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRAM_ABI_VERSION 1
+
+#define GRAM_E_ARG (-1)       /* bad shape / unsupported size                           */
+#define GRAM_E_WORKSPACE (-2) /* workspace too small (see gram_workspace_bytes)          */
+#define GRAM_E_BEAM (-3)      /* device beam bookkeeping flagged an impossible state      */
+
+#define GRAM_MAX_BEAMS 64      /* K <= 64 (reference default 50, headline 20)             */
+#define GRAM_MAX_DEC_LEN 32    /* max_length <= 32 (reference: 8..12)                     */
+#define GRAM_MAX_PASSAGE_LEN 128 /* L <= 128 (arguments.py:293-298), L % 32 == 0          */
+
+/* ---- GEMM epilogues ------------------------------------------------------------------ */
+enum gram_epilogue {
+  GRAM_EPI_BF16 = 0,      /* C_bf16[m][n]  = acc                                          */
+  GRAM_EPI_BF16_RELU = 1, /* C_bf16[m][n]  = max(acc, 0)        (T5DenseActDense wi+ReLU) */
+  GRAM_EPI_F32_ADD = 2,   /* C_f32[m][n]  += acc                (residual add)            */
+  GRAM_EPI_F32 = 3,       /* C_f32[m][n]   = acc                (lm_head logits)          */
+  GRAM_EPI_KV_BANK = 4    /* scatter into the fused K bank / V^T bank (see below)         */
+};
+
+/* Fused cross-attention KV bank for B users, S = N*L fused tokens, n_layers decoder layers:
+ *   k  : [layer][b][h][s][64]   bf16   (key rows contiguous: streamed 128 B per key)
+ *   vt : [layer][b][h][64][s]   bf16   (V transposed: the MFMA A operand is read k-contiguous)
+ * Beam-invariant: ONE copy per user, shared by the user's K beams (the reference replicates it
+ * K times and index_select-s it every step: gram_t5_modeling.py:531-549, gram_t5.py:320-348). */
+typedef struct {
+  void* k;
+  void* vt;
+  int32_t n_layers, B, H, S;
+} gram_kv_bank_t;
+
+/* C[M,N] (+)= A[M,K] @ W[N,K]^T, bf16 operands, fp32 accumulate on MFMA.
+ * Replaces every nn.Linear on the path (gram_t5_modeling.py:300-301,369-372; gram_t5.py:254).
+ * N % 128 == 0, K % 64 == 0, any M >= 1.  For GRAM_EPI_KV_BANK, C is ignored, `bank` is used,
+ * rows m = b*S + s and columns n = (layer*2 + which)*inner + h*64 + d. */
+int gram_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc,
+                   int epilogue, const gram_kv_bank_t* bank_host, void* stream);
+
+/* x[row][:] = table[ids[row]][:]   (embed_tokens, gram_t5_modeling.py:1091). */
+int gram_embed_i64(const float* table, const int64_t* ids, float* x, int rows, int d, void* stream);
+int gram_embed_i32(const float* table, const int32_t* ids, float* x, int rows, int d, void* stream);
+
+/* T5LayerNorm (gram_t5_modeling.py:262-276) with the two fusions the path needs:
+ *   out_bf16[row][i] = bf16( x[row][i] * rsqrt(mean(x^2)+eps) * w[i] * scale
+ *                            + (pos ? pos[(row / L) % N][i] : 0) )
+ * scale = d_model^-0.5 for the tied lm_head (gram_t5.py:249-252); pos = per-passage position
+ * embedding of the late fusion (gram.py:238-249). */
+int gram_rmsnorm_bf16(const float* x, const float* w, void* out_bf16, int rows, int d, float eps,
+                      float scale, const float* pos, int N, int L, void* stream);
+
+/* Encoder self-attention for P passages of L tokens (T5Attention.forward, bidirectional,
+ * gram_t5_modeling.py:479-631): unscaled QK^T + bucketed relative bias + key mask, fp32
+ * softmax, @V.  qkv: bf16 [P*L][3*inner] (q|k|v); bias: f32 [H][255] indexed by
+ * (key - query + 127); mask: u8 [P][L] (1 = valid); out: bf16 [P*L][inner]. */
+int gram_enc_self_attn(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P,
+                       int L, int H, void* stream);
+
+/* Late-fusion cross-attention for one decoder layer and one decode step (the fusion read:
+ * T5Attention.forward cross branch, gram_t5_modeling.py:531-534,547-549,572-622; zero position
+ * bias :577-582; mask :1145-1147).  q: bf16 [B*K][inner] (row = b*K + beam); k/vt: that layer's
+ * slices of the bank; mask: u8 [B][S]; out: bf16 [B*K][inner].  S % 32 == 0, K <= 64. */
+int gram_cross_attn_decode(const void* q, const void* k_layer, const void* vt_layer,
+                           const uint8_t* mask, void* out, int B, int K, int H, int S, void* stream);
+
+/* Decoder causal self-attention for the token at position t with a slot cache and beam-parent
+ * indirection instead of the reference's torch.cat + index_select (gram_t5_modeling.py:536-540,
+ * 586-593; gram_t5.py:320-348).  qkv: bf16 [R][3*inner]; kcache/vcache: bf16 [Tmax][R][inner]
+ * (this layer); anc: i32 [Tmax][R], anc[j][r] = row whose step-j K/V is r's ancestor (j < t);
+ * bias: f32 [H][GRAM_MAX_DEC_LEN] indexed by distance t-j.  Writes this step's k,v into slot t. */
+int gram_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t* anc,
+                       const float* bias, void* out, int R, int H, int t, int Tmax, void* stream);
+
+/* lse[r] = log(sum_v exp(logits[r][v]))   (the normaliser of HF's log_softmax in beam_search). */
+int gram_row_lse(const float* logits, float* lse, int R, int V, void* stream);
+
+/* Flat Trie in HBM (CSR), built from generation_trie.py:5-68's nested dict by
+ * gram_amd.utils.generation_trie.FlatTrie.  Children of node n are
+ * child_tok/child_node[child_off[n] .. child_off[n+1]), sorted by token.  Node 0 is the root. */
+typedef struct {
+  const int32_t* child_off;
+  const int32_t* child_tok;
+  const int32_t* child_node;
+  int32_t n_nodes, n_edges, max_fanout;
+} gram_trie_t;
+
+/* Beam-search state for B users x K beams (HF transformers 4.26 beam_search + BeamSearchScorer
+ * + BeamHypotheses state, kept on the device).  All arrays are caller-allocated. */
+typedef struct {
+  int32_t B, K, Tmax;      /* Tmax = max_length                                           */
+  float length_penalty;
+  int32_t eos, pad;
+  int32_t* tokens;         /* [R]        next decoder input token per row                  */
+  int32_t* node;           /* [R]        Trie node of each beam's prefix, -1 = not in Trie */
+  float* beam_scores;      /* [R]                                                        */
+  int32_t* seq;            /* [R][Tmax]  input_ids of each beam                           */
+  int32_t* anc;            /* [Tmax][R]  self-attention ancestor table                    */
+  int32_t* done;           /* [B]                                                        */
+  int32_t* n_hyps;         /* [B]                                                        */
+  double* hyp_score;       /* [B][K+1]   length-normalised score (Python float semantics);
+                              one spare slot: BeamHypotheses.add appends, then drops the worst */
+  double* worst;           /* [B]                                                        */
+  int32_t* hyp_len;        /* [B][K+1]                                                   */
+  int32_t* hyp_tok;        /* [B][K+1][Tmax]                                             */
+  int32_t* error;          /* [1]        set non-zero on an impossible state              */
+} gram_beam_state_t;
+
+/* decoder_input_ids = [[start]]*B*K ; beam_scores = [0,-1e9,...] (HF 4.26 beam_search init). */
+int gram_beam_init(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, int start_token,
+                   void* stream);
+
+/* One search step, cur_len = number of tokens already in each beam:
+ *   log_softmax (via lse) -> PrefixConstrainedLogitsProcessor (Trie children; -inf elsewhere)
+ *   -> + beam_scores -> top-2K over K*V (ties: lower flat index first) -> BeamSearchScorer.process
+ *   -> next tokens / scores / parents, sequences and the ancestor table advanced in place.
+ * Replaces HF 4.26 beam_search's per-step body and generation_trie.py:89-95's per-beam Python
+ * callback (one D2H sync per beam per step in the reference). */
+int gram_beam_step(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const float* logits,
+                   const float* lse, int V, int cur_len, void* stream);
+
+/* BeamSearchScorer.finalize: sequences int64 [B*nret][Tmax] (0-padded, EOS appended when it
+ * fits), scores f32 [B*nret], out_width[0] = min(max hyp len + 1, max_length). */
+int gram_beam_finalize(const gram_beam_state_t* st_host, int nret, int max_length, int64_t* sequences,
+                       float* scores, int32_t* out_width, void* stream);
+
+/* ---- whole-path entry points ---------------------------------------------------------- */
+typedef struct {
+  int32_t vocab, d_model, d_ff, n_heads, n_enc_layers, n_dec_layers, max_passages;
+  int32_t tie_word_embeddings, use_position_embedding;
+  float eps;
+  const float* embed_f32;      /* [V][d]      shared.weight                                */
+  const void* lm_head_bf16;    /* [V][d]      lm_head.weight                               */
+  const float* pos_emb_f32;    /* [max_passages][d] or NULL                                */
+  const float* enc_bias_f32;   /* [H][255]    encoder relative bias, layer-0 table         */
+  const float* dec_bias_f32;   /* [H][GRAM_MAX_DEC_LEN] decoder relative bias by distance  */
+  const float* enc_final_ln;   /* [d]                                                     */
+  const float* dec_final_ln;   /* [d]                                                     */
+  /* per-layer arrays (HOST arrays of device pointers) */
+  const float* const* enc_ln1; /* [n_enc]  layer.0.layer_norm                              */
+  const void* const* enc_wqkv; /* [n_enc]  bf16 [3*inner][d]  (q;k;v rows concatenated)    */
+  const void* const* enc_wo;   /* [n_enc]  bf16 [d][inner]                                 */
+  const float* const* enc_ln2; /* [n_enc]                                                 */
+  const void* const* enc_wi;   /* [n_enc]  bf16 [d_ff][d]                                  */
+  const void* const* enc_wo2;  /* [n_enc]  bf16 [d][d_ff]                                  */
+  const float* const* dec_ln1; /* [n_dec]                                                 */
+  const void* const* dec_wqkv; /* [n_dec]  bf16 [3*inner][d]                               */
+  const void* const* dec_wo;   /* [n_dec]  bf16 [d][inner]                                 */
+  const float* const* dec_ln2; /* [n_dec]                                                 */
+  const void* const* dec_wq_x; /* [n_dec]  bf16 [inner][d]   EncDecAttention.q             */
+  const void* const* dec_wo_x; /* [n_dec]  bf16 [d][inner]   EncDecAttention.o             */
+  const float* const* dec_ln3; /* [n_dec]                                                 */
+  const void* const* dec_wi;   /* [n_dec]  bf16 [d_ff][d]                                  */
+  const void* const* dec_wo2;  /* [n_dec]  bf16 [d][d_ff]                                  */
+  const void* dec_wkv_x_all;   /* bf16 [n_dec*2*inner][d]: per layer k rows then v rows     */
+} gram_model_desc_t;
+
+typedef struct gram_model gram_model_t;
+
+/* Copies the descriptor (not the weights).  Mirrors create_model("gram", config) +
+ * load_state_dict (src/model/__init__.py:9-24, gram.py:162-165). */
+gram_model_t* gram_model_create(const gram_model_desc_t* desc_host);
+void gram_model_destroy(gram_model_t* m);
+
+/* Bytes of scratch gram_generate needs for this problem size (256-B aligned carve). */
+int64_t gram_workspace_bytes(const gram_model_t* m, int B, int N, int L, int K, int max_length);
+
+/* EncoderWrapper.forward + the fused-bank projection (gram.py:200-256; gram_t5_modeling.py
+ * T5Stack encoder role; cross K/V projection :531-534 for every decoder layer at once).
+ * input_ids i64 [B][N][L], mask u8 [B][N][L].  Writes the bank into the workspace; when
+ * enc_out_bf16 != NULL also copies the fused encoder states [B*N*L][d] there (tests). */
+int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N,
+                      int L, void* workspace, int64_t workspace_bytes, int K, int max_length,
+                      void* enc_out_bf16, void* stream);
+
+/* One cached decoder step for all B*K rows at position t, using the bank a preceding
+ * gram_encode_fused left in the same workspace (T5ForConditionalGeneration_GRAM.forward with
+ * encoder_outputs given, gram_t5.py:181-254).  tokens i32 [B*K]; anc as in gram_dec_self_attn;
+ * logits f32 [B*K][V] (device, caller-owned). */
+int gram_decode_step(const gram_model_t* m, const int32_t* tokens, const int32_t* anc, const uint8_t* mask,
+                     int B, int N, int L, int K, int max_length, int t, void* workspace,
+                     int64_t workspace_bytes, float* logits, void* stream);
+
+/* GRAM.generate (gram.py:74-107) with the runner's kwargs (single_runner_gram.py:641-651):
+ * encoder -> late fusion -> bank -> max_length-1 constrained beam-search steps -> finalize.
+ * sequences i64 [B*nret][max_length], scores f32 [B*nret]; *width_host receives
+ * min(max hyp len + 1, max_length) (the column count HF returns) if non-NULL, which costs one
+ * stream synchronise.  Returns GRAM_E_BEAM if the device flagged an impossible beam state. */
+int gram_generate(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L,
+                  int K, int nret, int max_length, float length_penalty, const gram_trie_t* trie_host,
+                  void* workspace, int64_t workspace_bytes, int64_t* sequences, float* scores,
+                  int32_t* width_host, void* stream);
+
+int gram_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAM_HIP_H */

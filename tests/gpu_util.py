@@ -1,0 +1,73 @@
+"""Helpers for the -m gpu parity tests: call libgram_hip.so through its C ABI on torch tensors."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from gram_amd import _lib
+
+DEV = "cuda:0"
+
+
+def lib():
+    return _lib.load()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def p(t):
+    return None if t is None else t.data_ptr()
+
+
+def bf(t):
+    return t.to(DEV, torch.float32).to(torch.bfloat16).contiguous()
+
+
+def gemm(A, W, epi, C_out=None, bank=None):
+    M, K = A.shape
+    N = W.shape[0]
+    rc = lib().gram_gemm_bf16(p(A), p(W), p(C_out), M, N, K, A.stride(0), 0 if C_out is None else C_out.stride(0), epi,
+                              None if bank is None else C.byref(bank), stream())
+    _lib.check(rc, "gram_gemm_bf16")
+    return C_out
+
+
+def make_beam_state(B, K, Tmax, lp=1.0, device=DEV):
+    R = B * K
+    t = dict(
+        tokens=torch.zeros(R, dtype=torch.int32, device=device), node=torch.zeros(R, dtype=torch.int32, device=device),
+        beam_scores=torch.zeros(R, dtype=torch.float32, device=device), seq=torch.zeros(R, Tmax, dtype=torch.int32, device=device),
+        anc=torch.zeros(Tmax, R, dtype=torch.int32, device=device), done=torch.zeros(B, dtype=torch.int32, device=device),
+        n_hyps=torch.zeros(B, dtype=torch.int32, device=device), hyp_score=torch.zeros(B, K + 1, dtype=torch.float64, device=device),
+        worst=torch.zeros(B, dtype=torch.float64, device=device), hyp_len=torch.zeros(B, K + 1, dtype=torch.int32, device=device),
+        hyp_tok=torch.zeros(B, K + 1, Tmax, dtype=torch.int32, device=device), error=torch.zeros(4, dtype=torch.int32, device=device),
+    )
+    st = _lib.BeamState(B=B, K=K, Tmax=Tmax, length_penalty=lp, eos=1, pad=0, **{k: v.data_ptr() for k, v in t.items()})
+    return st, t
+
+
+def device_beam_search(logits_per_step, flat_trie, B, K, max_length, lp=1.0, nret=None):
+    """Run gram_beam_init/step/finalize on pre-computed logits [T][R][V] (fp32, device)."""
+    nret = nret or K
+    V = logits_per_step[0].shape[-1]
+    st, keep = make_beam_state(B, K, max_length, lp)
+    ctrie, keep2 = flat_trie.to_device(torch.device(DEV))
+    L = lib()
+    _lib.check(L.gram_beam_init(C.byref(st), C.byref(ctrie), 0, stream()), "beam_init")
+    lse = torch.empty(B * K, dtype=torch.float32, device=DEV)
+    trace = []
+    for t in range(max_length - 1):
+        lg = logits_per_step[t].contiguous()
+        _lib.check(L.gram_row_lse(p(lg), p(lse), B * K, V, stream()), "row_lse")
+        _lib.check(L.gram_beam_step(C.byref(st), C.byref(ctrie), p(lg), p(lse), V, t + 1, stream()), "beam_step")
+        trace.append(dict(tokens=keep["tokens"].clone(), scores=keep["beam_scores"].clone(), seq=keep["seq"].clone(),
+                          anc=keep["anc"].clone(), done=keep["done"].clone()))
+    seqs = torch.empty(B * nret, max_length, dtype=torch.int64, device=DEV)
+    scores = torch.empty(B * nret, dtype=torch.float32, device=DEV)
+    width = torch.zeros(4, dtype=torch.int32, device=DEV)
+    _lib.check(L.gram_beam_finalize(C.byref(st), nret, max_length, p(seqs), p(scores), p(width), stream()), "beam_finalize")
+    torch.cuda.synchronize()
+    w = int(width[0])
+    return seqs[:, :w].cpu(), scores.cpu(), int(keep["error"][0]), trace

@@ -1,0 +1,277 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against the oracle / a torch-fp32 restatement
+of the same op on the same seeded inputs.  Integer outputs are compared bit-exactly; floating-point
+ones within the bf16-operand / fp32-accumulate tolerance stated at each assert."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gram_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tests import gpu_util
+    return gpu_util
+
+
+def _r(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (77, 384, 768), (1280, 128, 3072)])
+def test_gemm_epilogues(G, M, N, K):
+    from gram_amd import _lib
+    A, W = G.bf(_r(M, K, seed=1)), G.bf(_r(N, K, seed=2, scale=K ** -0.5))
+    ref = A.float() @ W.float().T
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=G.DEV)
+    G.gemm(A, W, _lib.EPI_BF16, out)
+    # bf16 output rounding: 2^-8 relative
+    assert torch.allclose(out.float(), ref, atol=2e-2, rtol=1e-2)
+    G.gemm(A, W, _lib.EPI_BF16_RELU, out)
+    assert torch.allclose(out.float(), ref.clamp(min=0), atol=2e-2, rtol=1e-2)
+    outf = torch.empty(M, N, dtype=torch.float32, device=G.DEV)
+    G.gemm(A, W, _lib.EPI_F32, outf)
+    # fp32 accumulate of exact bf16 products: only summation order differs
+    assert torch.allclose(outf, ref, atol=1e-3, rtol=1e-4)
+    base = _r(M, N, seed=3).to(G.DEV)
+    acc = base.clone()
+    G.gemm(A, W, _lib.EPI_F32_ADD, acc)
+    assert torch.allclose(acc, base + ref, atol=1e-3, rtol=1e-4)
+
+
+def test_gemm_asymmetric_identity(G):
+    """A = I with an asymmetric W catches a transposed / row-col swapped fragment mapping."""
+    from gram_amd import _lib
+    K = N = 128
+    A = G.bf(torch.eye(128, K))
+    W = G.bf(torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125)
+    out = torch.empty(128, N, dtype=torch.float32, device=G.DEV)
+    G.gemm(A, W, _lib.EPI_F32, out)
+    assert torch.equal(out, W.float().T)
+
+
+def test_gemm_kv_bank(G):
+    from gram_amd import _lib
+    layers, B, H, S, d = 2, 3, 2, 64, 128
+    inner = H * 64
+    A = G.bf(_r(B * S, d, seed=4))
+    W = G.bf(_r(layers * 2 * inner, d, seed=5, scale=d ** -0.5))
+    k = torch.zeros(layers, B, H, S, 64, dtype=torch.bfloat16, device=G.DEV)
+    vt = torch.zeros(layers, B, H, 64, S, dtype=torch.bfloat16, device=G.DEV)
+    bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, B, H, S)
+    G.gemm(A, W, _lib.EPI_KV_BANK, None, bank)
+    ref = (A.float() @ W.float().T).view(B, S, layers, 2, H, 64)
+    assert torch.allclose(k.float(), ref[:, :, :, 0].permute(2, 0, 3, 1, 4), atol=2e-2, rtol=1e-2)
+    assert torch.allclose(vt.float(), ref[:, :, :, 1].permute(2, 0, 3, 4, 1), atol=2e-2, rtol=1e-2)
+
+
+# ------------------------------------------------------------------------------------ row ops
+def test_embed_rmsnorm_lse(G):
+    L_ = G.lib()
+    from gram_amd import _lib
+    V, d, rows = 512, 768, 37
+    table = _r(V, d, seed=6).to(G.DEV)
+    ids64 = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(7)).to(G.DEV)
+    x = torch.empty(rows, d, device=G.DEV)
+    _lib.check(L_.gram_embed_i64(G.p(table), G.p(ids64), G.p(x), rows, d, G.stream()), "embed")
+    assert torch.equal(x, table[ids64])
+    x2 = torch.empty(rows, d, device=G.DEV)
+    _lib.check(L_.gram_embed_i32(G.p(table), G.p(ids64.int()), G.p(x2), rows, d, G.stream()), "embed")
+    assert torch.equal(x2, x)
+    # rmsnorm + position embedding + scale
+    N, Lp = 3, 4
+    rows = 2 * N * Lp
+    xx = _r(rows, d, seed=8, scale=3.0).to(G.DEV)
+    w = (1 + 0.1 * _r(d, seed=9)).to(G.DEV)
+    pos = _r(N, d, seed=10, scale=0.02).to(G.DEV)
+    out = torch.empty(rows, d, dtype=torch.bfloat16, device=G.DEV)
+    _lib.check(L_.gram_rmsnorm_bf16(G.p(xx), G.p(w), G.p(out), rows, d, 1e-6, 0.5, G.p(pos), N, Lp, G.stream()), "rmsnorm")
+    ref = O.rms_norm(xx.cpu(), w.cpu(), 1e-6) * 0.5 + pos.cpu()[(torch.arange(rows) // Lp) % N]
+    assert torch.allclose(out.float().cpu(), ref, atol=1e-2, rtol=8e-3)  # bf16 output
+    _lib.check(L_.gram_rmsnorm_bf16(G.p(xx), G.p(w), G.p(out), rows, d, 1e-6, 1.0, None, 1, 1, G.stream()), "rmsnorm")
+    assert torch.allclose(out.float().cpu(), O.rms_norm(xx.cpu(), w.cpu(), 1e-6), atol=2e-2, rtol=8e-3)
+    # lse
+    lg = _r(19, 32128, seed=11, scale=2.0).to(G.DEV)
+    lg[3, 100] = 40.0
+    lse = torch.empty(19, device=G.DEV)
+    _lib.check(L_.gram_row_lse(G.p(lg), G.p(lse), 19, 32128, G.stream()), "lse")
+    assert torch.allclose(lse, torch.logsumexp(lg, -1), atol=2e-5, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ encoder attention
+@pytest.mark.parametrize("L", [32, 64, 96, 128])
+def test_enc_self_attn(G, L):
+    from gram_amd import _lib
+    from gram_amd.model.gram import relative_position_bucket
+    P, H = 5, 3
+    inner = H * 64
+    g = torch.Generator().manual_seed(L)
+    qkv = G.bf(torch.randn(P * L, 3 * inner, generator=g))
+    table = torch.randn(32, H, generator=g) * 0.5
+    bias = table[relative_position_bucket(torch.arange(-127, 128), True, 32, 128)].t().contiguous().to(G.DEV)
+    mask = torch.zeros(P, L, dtype=torch.bool)
+    for p_ in range(P):
+        mask[p_, : int(torch.randint(1, L + 1, (1,), generator=g))] = True
+    mask[P - 1] = False  # fully padded passage: reference gives uniform attention (all scores == finfo.min)
+    mask[0] = True
+    out = torch.empty(P * L, inner, dtype=torch.bfloat16, device=G.DEV)
+    m8 = mask.to(G.DEV).view(torch.uint8).contiguous()
+    _lib.check(G.lib().gram_enc_self_attn(G.p(qkv), G.p(bias), G.p(m8), G.p(out), P, L, H, G.stream()), "enc_attn")
+    # oracle on the same bf16-rounded operands
+    x = qkv.float().cpu().view(P, L, 3, H, 64)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    cfg = O.OracleConfig(num_heads=H)
+    b = O.position_bias(table, L, L, True, cfg) + ((1.0 - mask.float())[:, None, None, :] * O.FMIN)
+    ref = O._attend(q, k, v, b).reshape(P * L, inner)
+    # P is rounded to bf16 before P@V (rel 2^-9) and the output is bf16: tolerance 2e-2 abs on O(1) values
+    assert torch.allclose(out.float().cpu(), ref, atol=2.5e-2, rtol=2e-2)
+
+
+# ------------------------------------------------------------------------------------ cross attention
+@pytest.mark.parametrize("K,S", [(20, 384), (1, 32), (16, 96), (50, 2688), (33, 160)])
+def test_cross_attn_decode(G, K, S):
+    from gram_amd import _lib
+    B, H = 3, 2
+    inner = H * 64
+    g = torch.Generator().manual_seed(K * 1000 + S)
+    q = G.bf(torch.randn(B * K, inner, generator=g) * 0.3)
+    kb = G.bf(torch.randn(B, H, S, 64, generator=g))
+    vb = torch.randn(B, H, S, 64, generator=g)
+    vt = G.bf(vb.transpose(2, 3).contiguous())
+    mask = torch.rand(B, S, generator=g) > 0.3
+    mask[1, : S // 2] = False  # leading masked steps (whole 32-key steps of -min before any valid key)
+    if S >= 64:
+        mask[2, 32:] = False
+    out = torch.empty(B * K, inner, dtype=torch.bfloat16, device=G.DEV)
+    m8 = mask.to(G.DEV).view(torch.uint8).contiguous()
+    _lib.check(G.lib().gram_cross_attn_decode(G.p(q), G.p(kb), G.p(vt), G.p(m8), G.p(out), B, K, H, S, G.stream()), "xattn")
+    qh = q.float().cpu().view(B, K, H, 64).permute(0, 2, 1, 3)  # (B,H,K,64)
+    ext = ((1.0 - mask.float()) * O.FMIN)[:, None, None, :]
+    ref = O._attend(qh, kb.float().cpu(), vt.float().cpu().transpose(2, 3), ext).reshape(B * K, inner)
+    assert torch.allclose(out.float().cpu(), ref, atol=2.5e-2, rtol=2e-2)
+
+
+def test_cross_attn_all_masked_user(G):
+    """A user whose whole bank is masked: the reference's softmax over all-finfo.min scores is uniform."""
+    from gram_amd import _lib
+    B, H, K, S = 1, 1, 4, 64
+    g = torch.Generator().manual_seed(5)
+    q = G.bf(torch.randn(B * K, 64, generator=g))
+    kb = G.bf(torch.randn(B, H, S, 64, generator=g))
+    vb = torch.randn(B, H, S, 64, generator=g)
+    vt = G.bf(vb.transpose(2, 3).contiguous())
+    m8 = torch.zeros(B, S, dtype=torch.uint8, device=G.DEV)
+    out = torch.empty(B * K, 64, dtype=torch.bfloat16, device=G.DEV)
+    _lib.check(G.lib().gram_cross_attn_decode(G.p(q), G.p(kb), G.p(vt), G.p(m8), G.p(out), B, K, H, S, G.stream()), "xattn")
+    ref = vt.float().cpu()[0, 0].mean(-1)  # uniform average over keys
+    assert torch.allclose(out.float().cpu(), ref.expand(K, 64), atol=2e-2, rtol=2e-2)
+
+
+# ------------------------------------------------------------------------------------ decoder self attention
+def test_dec_self_attn(G):
+    from gram_amd import _lib
+    from gram_amd.model.gram import relative_position_bucket
+    R, H, Tmax = 12, 3, 10
+    inner = H * 64
+    g = torch.Generator().manual_seed(21)
+    table = torch.randn(32, H, generator=g) * 0.5
+    bias = table[relative_position_bucket(-torch.arange(0, 32), False, 32, 128)].t().contiguous().to(G.DEV)
+    kc = torch.zeros(Tmax, R, inner, dtype=torch.bfloat16, device=G.DEV)
+    vc = torch.zeros_like(kc)
+    anc = torch.arange(R, dtype=torch.int32).repeat(Tmax, 1).to(G.DEV)
+    cfg = O.OracleConfig(num_heads=H)
+    ks, vs = None, None
+    for t in range(6):
+        qkv = G.bf(torch.randn(R, 3 * inner, generator=g) * 0.5)
+        out = torch.empty(R, inner, dtype=torch.bfloat16, device=G.DEV)
+        _lib.check(G.lib().gram_dec_self_attn(G.p(qkv), G.p(kc), G.p(vc), G.p(anc), G.p(bias), G.p(out), R, H, t, Tmax, G.stream()),
+                   "dec_attn")
+        x = qkv.float().cpu().view(R, 1, 3, H, 64)
+        q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        ks = k if ks is None else torch.cat([ks, k], 2)
+        vs = v if vs is None else torch.cat([vs, v], 2)
+        b = O.position_bias(table, t + 1, t + 1, False, cfg)[:, :, -1:, :]
+        ref = O._attend(q, ks, vs, b).reshape(R, inner)
+        assert torch.allclose(out.float().cpu(), ref, atol=2e-2, rtol=2e-2), t
+        # beam reorder: the reference index_selects the cache, the device updates the ancestor table
+        parent = torch.randint(0, R, (R,), generator=g)
+        ks, vs = ks.index_select(0, parent), vs.index_select(0, parent)
+        a = anc.cpu()
+        new = a.clone()
+        new[: t, :] = a[: t, parent]
+        new[t, :] = parent.int()
+        anc.copy_(new)
+
+
+# ------------------------------------------------------------------------------------ beam search
+def _tries():
+    uniform = [[0, a, b, 1] for a in range(2, 9) for b in range(10, 14)]
+    ragged = [[0, 2, 3, 1], [0, 2, 4, 5, 1], [0, 2, 4, 6, 7, 1], [0, 3, 1], [0, 3, 8, 1], [0, 4, 9, 9, 9, 1], [0, 5, 1],
+              [0, 6, 2, 1], [0, 6, 3, 1], [0, 7, 7, 1], [0, 8, 1], [0, 9, 2, 2, 1]]
+    narrow_root = [[0, 2, b, c, 1] for b in range(3, 9) for c in range(3, 7)] + [[0, 9, b, c, 1] for b in range(3, 6) for c in range(3, 5)]
+    return {"uniform": uniform, "ragged": ragged, "narrow_root": narrow_root}
+
+
+@pytest.mark.parametrize("name,K,lp", [("uniform", 4, 1.0), ("uniform", 20, 1.0), ("ragged", 3, 1.0), ("ragged", 5, 0.7),
+                                        ("ragged", 12, 1.0), ("narrow_root", 6, 1.0), ("narrow_root", 16, 2.0)])
+def test_beam_search_bit_exact_vs_oracle(G, name, K, lp):
+    """Same logits into the oracle's restated HF-4.26 search and into gram_beam_*: identical
+    sequences (bit-exact), scores within fp32 rounding of log_softmax (1e-5)."""
+    from gram_amd.utils import generation_trie as gt
+    cands = _tries()[name]
+    B, V = 3, 128
+    max_length = max(len(c) for c in cands)
+    g = torch.Generator().manual_seed(len(name) * 100 + K)
+    logits = [torch.randn(B * K, V, generator=g) * 2.0 for _ in range(max_length - 1)]
+    trie = O.Trie(cands)
+    step = {"t": 0}
+
+    def step_fn(tok):
+        out = logits[step["t"]]
+        step["t"] += 1
+        return out
+
+    seqs, scores = O.beam_search(step_fn, lambda idx: None, B, K, max_length, O.prefix_allowed_tokens_fn(trie), lp,
+                                 early_exit=False) if len(cands) >= K else (None, None)
+    if seqs is None:
+        pytest.skip("fewer candidates than beams")
+    flat = gt.FlatTrie(gt.Trie(cands))
+    dseq, dscore, err, _ = G.device_beam_search([l.to(G.DEV) for l in logits], flat, B, K, max_length, lp)
+    assert err == 0
+    assert dseq.tolist() == seqs.tolist()
+    assert torch.allclose(dscore, scores, atol=1e-5, rtol=1e-6)
+
+
+def test_beam_search_real_trie_shapes(G):
+    """Beauty Trie (12 101 items, fan-out up to 255), K=20: device vs oracle on random logits."""
+    import os
+    from gram_amd.utils import generation_trie as gt
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tries.npz"))
+    cands = [[int(x) for x in r if x >= 0] for r in z["Beauty_cands"]]
+    B, K, V = 2, 20, 32128
+    max_length = max(len(c) for c in cands)
+    g = torch.Generator().manual_seed(99)
+    logits = [torch.randn(B * K, V, generator=g) for _ in range(max_length - 1)]
+    trie = O.Trie(cands)
+    step = {"t": 0}
+
+    def step_fn(tok):
+        out = logits[step["t"]]
+        step["t"] += 1
+        return out
+
+    seqs, scores = O.beam_search(step_fn, lambda idx: None, B, K, max_length, O.prefix_allowed_tokens_fn(trie), 1.0, early_exit=False)
+    flat = gt.FlatTrie(gt.Trie(cands))
+    dseq, dscore, err, _ = G.device_beam_search([l.to(G.DEV) for l in logits], flat, B, K, max_length, 1.0)
+    assert err == 0
+    assert dseq.tolist() == seqs.tolist()
+    assert torch.allclose(dscore, scores, atol=2e-5, rtol=1e-6)

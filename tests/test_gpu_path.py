@@ -1,0 +1,268 @@
+"""-m gpu: the whole scoring path (gram_amd.GRAM.generate -> gram_generate in libgram_hip.so) against
+the oracle on the same weights and inputs, plus the golden vectors made from the reference.
+
+The HIP path computes with bf16 operands / fp32 accumulation, the reference in fp32, so floating-point
+results are compared within stated tolerances and the *integer* results (which items, in which order)
+through tolerance-aware checks: a returned sequence must be a Trie member, its score must match the
+oracle's score of that same sequence, and any disagreement in membership/order must be between
+candidates whose oracle scores are closer than the tolerance."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gram_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gram_amd
+    return gram_amd
+
+
+def _cfgs(name):
+    if name == "tiny":
+        oc = O.OracleConfig(vocab_size=256, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2,
+                            max_item_num=5)
+    elif name == "small":
+        oc = O.OracleConfig.named("t5-small", max_item_num=4)
+    else:
+        oc = O.OracleConfig.named(name)
+    from gram_amd import T5Config
+    gc = T5Config(vocab_size=oc.vocab_size, d_model=oc.d_model, d_ff=oc.d_ff, num_layers=oc.num_layers,
+                  num_decoder_layers=oc.num_decoder_layers, num_heads=oc.num_heads, max_item_num=oc.max_item_num)
+    return oc, gc
+
+
+def _model(gpu, name, seed):
+    oc, gc = _cfgs(name)
+    sd = O.init_state_dict(oc, seed)
+    m = gpu.create_model("gram", gc)
+    m.load_state_dict(sd)
+    return oc, sd, m.to(DEV).eval()
+
+
+def _inputs(g, B, N, L, V, ragged=True):
+    ids = torch.randint(2, V, (B, N, L), generator=g)
+    mask = torch.ones(B, N, L, dtype=torch.bool)
+    if ragged:
+        for b in range(B):
+            for n in range(N):
+                ln = int(torch.randint(max(2, L // 3), L + 1, (1,), generator=g))
+                mask[b, n, ln:] = False
+                ids[b, n, ln - 1] = 1
+                ids[b, n, ln:] = 0
+        if N > 1:
+            mask[B - 1, N - 1] = False  # one fully padded passage
+            ids[B - 1, N - 1] = 0
+    return ids, mask
+
+
+def _encode_device(m, ids, mask, K=2, max_length=6):
+    from gram_amd import _lib
+    lib = _lib.load()
+    handle = m._pack()
+    B, N, L = ids.shape
+    ws = m._get_workspace(handle, B, N, L, K, max_length)
+    d = m.config.d_model
+    enc = torch.empty(B * N * L, d, dtype=torch.bfloat16, device=DEV)
+    idd = ids.to(DEV).contiguous()
+    mk = mask.to(DEV).view(torch.uint8).contiguous()
+    rc = lib.gram_encode_fused(handle, idd.data_ptr(), mk.data_ptr(), B, N, L, ws.data_ptr(), ws.numel(), K, max_length,
+                               enc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "gram_encode_fused")
+    return enc.float().cpu().view(B, N * L, d), ws, mk, handle
+
+
+@pytest.mark.parametrize("name,B,N,L", [("tiny", 2, 3, 32), ("tiny", 3, 2, 64), ("small", 2, 2, 128), ("t5-base", 1, 3, 32)])
+def test_encoder_fused_vs_oracle(gpu, name, B, N, L):
+    oc, sd, m = _model(gpu, name, 11)
+    g = torch.Generator().manual_seed(3)
+    ids, mask = _inputs(g, B, N, L, min(oc.vocab_size, 32100))
+    ref = O.encode_fused(sd, oc, ids, mask)
+    enc, *_ = _encode_device(m, ids, mask)
+    valid = mask.reshape(B, -1)
+    err = (enc - ref)[valid]
+    rel = err.norm() / ref[valid].norm()
+    # bf16 operands through num_layers blocks; hidden states are O(1) after the final RMSNorm
+    assert rel < 2e-2, float(rel)
+    assert err.abs().max() < 0.15, float(err.abs().max())
+
+
+def test_encoder_matches_reference_golden(gpu, golden_dir):
+    """Directly against the reference's own output (tests/golden/ref_tiny.npz)."""
+    z = np.load(os.path.join(golden_dir, "ref_tiny.npz"))
+    oc, sd, m = _model(gpu, "tiny", int(z["seed"]))
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    enc, *_ = _encode_device(m, ids, mask)
+    ref = torch.from_numpy(z["enc_fused"])
+    valid = mask.reshape(mask.shape[0], -1)
+    rel = (enc - ref)[valid].norm() / ref[valid].norm()
+    assert rel < 2e-2, float(rel)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_decode_steps_vs_oracle(gpu, name):
+    """gram_decode_step logits for a fixed token stream with beam reorders, vs the oracle's cached
+    decoder (= the reference's tuple cache + _reorder_cache, pinned by tests/golden)."""
+    from gram_amd import _lib
+    oc, sd, m = _model(gpu, name, 11)
+    g = torch.Generator().manual_seed(8)
+    B, N, L, K, T = 2, 2, 32, 3, 5
+    V = oc.vocab_size
+    ids, mask = _inputs(g, B, N, L, min(V, 32100))
+    _, ws, mk, handle = _encode_device(m, ids, mask, K=K, max_length=T + 1)
+    enc_ref = O.encode_fused(sd, oc, ids, mask)
+    ext = ((1.0 - mask.reshape(B, -1).float().repeat_interleave(K, 0)) * O.FMIN)[:, None, None, :]
+    st = O.DecodeState(O.cross_kv(sd, oc, enc_ref), ext, K)
+    R = B * K
+    anc = torch.arange(R, dtype=torch.int32).repeat(T + 1, 1).to(DEV)
+    logits = torch.empty(R, V, dtype=torch.float32, device=DEV)
+    lib = _lib.load()
+    for t in range(T):
+        toks = torch.randint(2, min(V, 32100), (R,), generator=g)
+        if t == 0:
+            toks[:] = 0
+        ref = O.decoder_step(sd, oc, toks, st)
+        rc = lib.gram_decode_step(handle, toks.int().to(DEV).data_ptr(), anc.data_ptr(), mk.data_ptr(), B, N, L, K, T + 1, t,
+                                  ws.data_ptr(), ws.numel(), logits.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "gram_decode_step")
+        got = logits.cpu()
+        # logits are O(1) (tied head, d^-0.5 rescale); bf16 operand error accumulates over the decoder layers
+        assert (got - ref).abs().max() < 0.12, (t, float((got - ref).abs().max()))
+        lp_err = (torch.log_softmax(got, -1) - torch.log_softmax(ref, -1)).abs().max()
+        assert lp_err < 0.12, (t, float(lp_err))
+        parent = torch.cat([torch.randperm(K, generator=g) + b * K for b in range(B)])
+        st.reorder(parent)
+        a = anc.cpu()
+        new = a.clone()
+        new[:t, :] = a[:t, parent]
+        new[t, :] = parent.int()
+        anc.copy_(new)
+
+
+def _random_items(g, n_items, depth_lo, depth_hi, tok_hi):
+    items = set()
+    while len(items) < n_items:
+        d = int(torch.randint(depth_lo, depth_hi + 1, (1,), generator=g))
+        items.add(tuple(int(x) for x in torch.randint(2, tok_hi, (d,), generator=g)))
+    return [[0] + list(it) + [1] for it in sorted(items)]
+
+
+def _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol, lp=1.0):
+    """Tolerance-aware comparison of device vs oracle top-K lists (see module docstring)."""
+    cand_set = {tuple(c) for c in cands}
+    B = ids.shape[0]
+    seqs, scores = out["sequences"].cpu(), out["sequences_scores"].cpu()
+    rseqs, rscores = ref["sequences"], ref["sequences_scores"]
+
+    def strip(row):
+        row = [int(x) for x in row]
+        while row and row[-1] == 0:
+            row.pop()
+        return tuple(row)
+
+    n_order_diff = 0
+    for b in range(B):
+        dev = [strip(r) for r in seqs[b * K:(b + 1) * K]]
+        orc = [strip(r) for r in rseqs[b * K:(b + 1) * K]]
+        osc = {s: float(v) for s, v in zip(orc, rscores[b * K:(b + 1) * K])}
+        assert len(set(dev)) == K, "duplicate hypotheses"
+        kth = float(rscores[(b + 1) * K - 1])
+        dsc = scores[b * K:(b + 1) * K]
+        assert all(dsc[i] >= dsc[i + 1] for i in range(K - 1)), "scores not descending"
+        for i, s in enumerate(dev):
+            assert s in cand_set, f"user {b}: {s} is not a Trie member"
+            if s in osc:
+                exact = osc[s]
+            else:  # not in the oracle's top-K: must be a near-miss of the K-th score
+                exact = O.sequence_logprob(sd, oc, ids[b:b + 1], mask[b:b + 1], list(s)) / (len(s) - 1) ** lp
+                assert exact > kth - 2 * tol, (b, s, exact, kth)
+            assert abs(float(dsc[i]) - exact) < tol, (b, s, float(dsc[i]), exact)
+        # order: any inversion w.r.t. oracle scores must be within tolerance
+        ex = [osc.get(s) for s in dev]
+        for i in range(K - 1):
+            if ex[i] is not None and ex[i + 1] is not None and ex[i] < ex[i + 1]:
+                assert ex[i + 1] - ex[i] < 2 * tol
+                n_order_diff += 1
+    return n_order_diff
+
+
+@pytest.mark.parametrize("name,B,N,L,K,n_items,depth", [
+    ("tiny", 4, 3, 32, 4, 40, (3, 3)), ("tiny", 3, 2, 48, 6, 60, (2, 4)), ("tiny", 2, 1, 32, 20, 200, (3, 4)),
+    ("small", 2, 2, 64, 8, 100, (3, 4)),
+])
+def test_generate_vs_oracle(gpu, name, B, N, L, K, n_items, depth):
+    from gram_amd.utils import generation_trie as gt
+    oc, sd, m = _model(gpu, name, 11)
+    g = torch.Generator().manual_seed(B * 100 + K)
+    ids, mask = _inputs(g, B, N, L, min(oc.vocab_size, 32100))
+    cands = _random_items(g, n_items, depth[0], depth[1], 60)
+    max_length = max(len(c) for c in cands)
+    ref = O.generate(sd, oc, ids, mask, max_length, O.prefix_allowed_tokens_fn(O.Trie(cands)), K, K, 1.0)
+    fn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
+    out = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max_length, prefix_allowed_tokens_fn=fn,
+                     num_beams=K, num_return_sequences=K, output_scores=True, return_dict_in_generate=True, length_penalty=1.0)
+    assert out["sequences"].shape[0] == B * K and out["sequences"].dtype == torch.int64
+    assert out["sequences"].shape[1] == ref["sequences"].shape[1]
+    assert bool((out["sequences"][:, 0] == 0).all())
+    _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=0.06)
+
+
+def test_generate_matches_reference_golden(gpu, golden_dir):
+    """Whole path vs the golden produced by reference forward + reference Trie + HF beam search."""
+    from gram_amd.utils import generation_trie as gt
+    z = np.load(os.path.join(golden_dir, "ref_generate.npz"))
+    oc, sd, m = _model(gpu, "tiny", int(z["seed"]))
+    for ci in range(int(z["n_cases"])):
+        ids, mask = torch.from_numpy(z[f"c{ci}_ids"]), torch.from_numpy(z[f"c{ci}_mask"])
+        cands = z[f"c{ci}_cands"].tolist()
+        K = int(z[f"c{ci}_K"])
+        fn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
+        out = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=len(cands[0]), prefix_allowed_tokens_fn=fn,
+                         num_beams=K, num_return_sequences=K, length_penalty=1.0)
+        ref = {"sequences": torch.from_numpy(z[f"c{ci}_sequences"]), "sequences_scores": torch.from_numpy(z[f"c{ci}_scores"])}
+        _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=0.06)
+
+
+def test_metric_parity_population(gpu):
+    """Recall@5 / NDCG@5 of device vs oracle over a user population whose gold items sit at known
+    oracle ranks (so the metric is sensitive to every rank flip).  The north-star bound (1e-4) is
+    quoted for a trained model on Beauty; on random weights near-ties are far more frequent, so the
+    bound asserted here is the measured-flip-rate one, and the deltas are printed."""
+    from gram_amd.utils import evaluate as ev, generation_trie as gt
+    oc, sd, m = _model(gpu, "tiny", 11)
+    g = torch.Generator().manual_seed(77)
+    cands = _random_items(g, 300, 3, 4, 40)
+    max_length = max(len(c) for c in cands)
+    K, B, nb = 10, 16, 8
+    ofn = O.prefix_allowed_tokens_fn(O.Trie(cands))
+    dfn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
+    metrics = ["hit@5", "hit@10", "ndcg@5", "ndcg@10"]
+    o_sum, d_sum, total, flips = np.zeros(4), np.zeros(4), 0, 0
+    strip = lambda s: tuple(int(t) for t in s if int(t) not in (0, 1))
+    for it in range(nb):
+        ids, mask = _inputs(g, B, 3, 32, 256)
+        ref = O.generate(sd, oc, ids, mask, max_length, ofn, K, K, 1.0)
+        out = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max_length, prefix_allowed_tokens_fn=dfn,
+                         num_beams=K, num_return_sequences=K)
+        opred = [strip(s) for s in ref["sequences"]]
+        dpred = [strip(s) for s in out["sequences"].cpu()]
+        gold = [opred[b * K + (b + it) % K] for b in range(B)]  # gold = oracle's rank-((b+it)%K) item
+        orel = ev.rel_results(opred, gold, ref["sequences_scores"].tolist(), K)
+        drel = ev.rel_results(dpred, gold, out["sequences_scores"].cpu().tolist(), K)
+        flips += int((ev.hit_ranks(orel) != ev.hit_ranks(drel)).sum())
+        o_sum += ev.get_metrics_results(orel, metrics)
+        d_sum += ev.get_metrics_results(drel, metrics)
+        total += B
+    delta = np.abs(o_sum - d_sum) / total
+    print(f"\n[metric parity] users={total} rank flips={flips} |delta| hit@5/hit@10/ndcg@5/ndcg@10 = {delta}")
+    assert flips <= 0.15 * total
+    assert (delta < 0.05).all(), delta
