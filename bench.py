@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- users/sec of GRAM's generative scoring path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): Beauty item Trie
+(12 101 items, T = 9 decode steps), T5-base, 3 granularity passages of 128 tokens per user
+(S = 384 fused keys), beam = 20 returning top-20.  One "step" = one ``GRAM.generate`` over a batch
+of B synthetic users already resident in HBM (random-init weights of the exact architecture,
+uniform token ids, all-valid masks: there is no network for checkpoints or tokenisers).  Users are
+independent, so N GPUs run N disjoint batches (weak scaling, no data-path collective).
+
+One JSON line is printed by rank 0.  Besides the contract keys it carries
+  roofline      the dominant kernel by summed device time, measured live with HIP events on the
+                launch stream over the timed region (gram_prof_* in libgram_hip.so)
+  roofline_cross_attn   the north star's named roofline: the fusion cross-attention kernel
+                against the HBM peak, algorithmic bytes = B*H*S*64*2(K,V)*2 B per launch
+  kernel_ms_per_step    device-time breakdown by kernel kind
+  cpu_baseline  the CPU oracle (reference-faithful mode: beam-replicated KV, per-step cache
+                reorder, B = 1 per call like the reference runner) timed on this host's cores on a
+                bounded sample, rank 0 at N = 1 only
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=128, help="users per generate() call per GPU")
+    ap.add_argument("--backbone", default="t5-base")
+    ap.add_argument("--dataset", default="Beauty")
+    ap.add_argument("--passages", type=int, default=3)
+    ap.add_argument("--passage-len", type=int, default=128)
+    ap.add_argument("--beams", type=int, default=20)
+    ap.add_argument("--cpu-users", type=int, default=2, help="users in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    import gram_amd
+    from gram_amd import _lib
+    from gram_amd.utils import generation_trie as gt
+
+    lib = _lib.load()
+    cfg = gram_amd.T5Config.named(args.backbone)
+    torch.manual_seed(2023)
+    model = gram_amd.create_model("gram", cfg)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_users > 0 and world == 1) else None
+    model = model.to(dev).eval()
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "tries.npz"))
+    cands = [[int(x) for x in row if x >= 0] for row in z[f"{args.dataset}_cands"]]
+    trie = gt.Trie(cands)
+    fn = gt.prefix_allowed_tokens_fn(trie)
+    max_length = max(len(c) for c in cands)
+
+    B, N, L, K = args.batch, args.passages, args.passage_len, args.beams
+    g = torch.Generator().manual_seed(1000 + rank)
+    ids = torch.randint(2, 32100, (B, N, L), generator=g)
+    ids[:, :, -1] = 1
+    mask = torch.ones(B, N, L, dtype=torch.bool)
+    ids_d, mask_d = ids.to(dev), mask.to(dev)
+
+    def step():
+        return model.generate(input_ids=ids_d, attention_mask=mask_d, max_length=max_length, prefix_allowed_tokens_fn=fn,
+                              num_beams=K, num_return_sequences=K, output_scores=True, return_dict_in_generate=True,
+                              length_penalty=1.0)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    kinds = {"gemm": _lib.K_GEMM, "enc_attn": _lib.K_ENC_ATTN, "cross_attn": _lib.K_CROSS_ATTN,
+             "dec_self_attn": _lib.K_DEC_SELF_ATTN, "rowops": _lib.K_ROWOPS, "lse": _lib.K_LSE, "beam": _lib.K_BEAM}
+    prof = not args.no_prof
+    if prof:
+        launches_per_step = 40 * (cfg.num_layers + cfg.num_decoder_layers * max_length) + 64
+        _lib.check(lib.gram_prof_enable(sum(1 << k for k in kinds.values()), launches_per_step * args.steps), "prof_enable")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    kernel = {}
+    if prof:
+        for name, kind in kinds.items():
+            ms, n, work, dropped = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_int64(0)
+            _lib.check(lib.gram_prof_collect(kind, C.byref(ms), C.byref(n), C.byref(work), C.byref(dropped)), "prof_collect")
+            kernel[name] = dict(ms=ms.value, launches=n.value, work=work.value, dropped=dropped.value)
+        lib.gram_prof_enable(0, 0)
+
+    if rank != 0:
+        if distributed:
+            dist.destroy_process_group()
+        return
+
+    users = world * B * args.steps
+    result = {
+        "metric": "users/sec @ beam=20 top-20 gen, Beauty T5-base; Recall@5 parity",
+        "value": users / dt,
+        "unit": "users/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.dataset} Trie ({len(cands)} items, T={max_length - 1}), {args.backbone}, "
+                        f"{N} granularity passages x {L} tokens (S={N * L}), beam={K} top-{K}",
+            "users_per_step_per_gpu": B, "parallelism": f"dp{world} (users sharded, no data-path collective)",
+            "precision": "bf16 operands / fp32 accumulate, fp32 residual stream, softmax and scores",
+        },
+        "output_check": {"sequences_shape": list(out["sequences"].shape),
+                         "all_in_trie": bool(all(tuple(int(t) for t in s if t != 0) in {tuple(c) for c in cands}
+                                                 for s in out["sequences"][: 2 * K].cpu().tolist()))},
+    }
+    if kernel:
+        steps = args.steps
+        result["kernel_ms_per_step"] = {k: round(v["ms"] / steps, 4) for k, v in kernel.items()}
+        result["kernel_ms_per_step"]["sum"] = round(sum(v["ms"] for v in kernel.values()) / steps, 4)
+        gm, xa = kernel["gemm"], kernel["cross_attn"]
+        gemm_tf = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+        xa_gbs = xa["work"] / (xa["ms"] * 1e-3) / 1e9 if xa["ms"] > 0 else 0.0
+        roof_gemm = {"kernel": "gemm_bf16_kernel", "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TF,
+                     "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TF, "traffic": None,
+                     "launches": gm["launches"], "avg_launch_us": 1e3 * gm["ms"] / max(gm["launches"], 1),
+                     "share_of_kernel_time": gm["ms"] / max(sum(v["ms"] for v in kernel.values()), 1e-9)}
+        roof_xa = {"kernel": "cross_attn_kernel", "bound": "hbm", "achieved": xa_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": xa_gbs / HBM_PEAK_GBS, "traffic": None, "launches": xa["launches"],
+                   "avg_launch_us": 1e3 * xa["ms"] / max(xa["launches"], 1),
+                   "algorithmic_bytes_per_launch": xa["work"] / max(xa["launches"], 1),
+                   "share_of_kernel_time": xa["ms"] / max(sum(v["ms"] for v in kernel.values()), 1e-9)}
+        dominant = max(kernel.items(), key=lambda kv: kv[1]["ms"])[0]
+        result["roofline"] = roof_xa if dominant == "cross_attn" else roof_gemm
+        result["roofline_cross_attn"] = roof_xa
+        result["roofline_gemm"] = roof_gemm
+
+    if state is not None:
+        from oracle import gram_oracle as O
+        oc = O.OracleConfig.named(args.backbone)
+        ofn = O.prefix_allowed_tokens_fn(O.Trie(cands))
+        threads = torch.get_num_threads()
+        t0 = time.perf_counter()
+        for u in range(args.cpu_users):  # B = 1 per call, like the reference runner (arguments.py:84-86)
+            O.generate(state, oc, ids[u:u + 1], mask[u:u + 1], max_length, ofn, K, K, 1.0, reference_faithful=True)
+        cdt = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": args.cpu_users / cdt, "unit": "users/s", "cores": threads, "kind": "port",
+            "sample": f"{args.cpu_users} users of the same workload, B=1 per call, oracle in reference-faithful mode "
+                      f"(fp32, beam-replicated KV, per-step cache reorder), {cdt:.1f} s of CPU work, host has {os.cpu_count()} cpus",
+        }
+    print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@ GRAM_MAX_BEAMS = 64
 GRAM_MAX_DEC_LEN = 32
 GRAM_MAX_PASSAGE_LEN = 128
 EPI_BF16, EPI_BF16_RELU, EPI_F32_ADD, EPI_F32, EPI_KV_BANK = range(5)
+K_GEMM, K_ENC_ATTN, K_CROSS_ATTN, K_DEC_SELF_ATTN, K_ROWOPS, K_LSE, K_BEAM = range(7)
 E_ARG, E_WORKSPACE, E_BEAM = -1, -2, -3
 
 vp = C.c_void_p
@@ -74,6 +75,9 @@ SIGNATURES = {
     "gram_workspace_bytes": (i64, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gram_encode_fused": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, C.c_int, vp, vp]),
     "gram_decode_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
+    "gram_prof_enable": (C.c_int, [C.c_uint32, C.c_int]),
+    "gram_prof_reset": (C.c_int, []),
+    "gram_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64)]),
     "gram_generate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.POINTER(Trie),
                                 vp, i64, vp, vp, C.POINTER(i32), vp]),
 }

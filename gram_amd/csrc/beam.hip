@@ -15,6 +15,7 @@
 //                                       advanced in place; K/V caches are never moved
 // One workgroup per user; users are independent, so this shards trivially.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -333,6 +334,7 @@ extern "C" int gram_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr
     if (e != hipSuccess) return (int)e;
     attr_bytes = smem;
   }
+  gram_prof::Scope prof(GRAM_K_BEAM, (hipStream_t)stream, 0.0);
   hipLaunchKernelGGL(beam_step_kernel, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc);
   GRAM_CHECK_LAUNCH();
   return 0;

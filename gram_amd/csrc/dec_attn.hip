@@ -20,6 +20,7 @@
 //     torch.cat + index_select of the whole cache (gram_t5_modeling.py:536-540,
 //     gram_t5.py:320-348); unidirectional relative bias, last query row (:586-593).
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -242,6 +243,7 @@ extern "C" int gram_cross_attn_decode(const void* q, const void* k_layer, const 
                                       int B, int K, int H, int S, void* stream) {
   if (B < 1 || K < 1 || K > GRAM_MAX_BEAMS || H < 1 || S < 32 || (S & 31)) return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  gram_prof::Scope prof(GRAM_K_CROSS_ATTN, st, 4.0 * B * H * S * 64 * 2);
   switch ((K + 15) / 16) {
     case 1: return launch_cross<1>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
     case 2: return launch_cross<2>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
@@ -253,6 +255,7 @@ extern "C" int gram_cross_attn_decode(const void* q, const void* k_layer, const 
 extern "C" int gram_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias, void* out,
                                   int R, int H, int t, int Tmax, void* stream) {
   if (R < 1 || H < 1 || H > 16 || t < 0 || t >= Tmax || Tmax > GRAM_MAX_DEC_LEN) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_DEC_SELF_ATTN, (hipStream_t)stream, 4.0 * R * H * 64 * (t + 1));
   hipLaunchKernelGGL(dec_self_attn_kernel, dim3(R), dim3(H * 16), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)kcache,
                      (bf16*)vcache, anc, bias, (bf16*)out, R, H, t);
   GRAM_CHECK_LAUNCH();

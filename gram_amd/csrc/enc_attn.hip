@@ -12,6 +12,7 @@
 // S^T tile t of a 32-key step are the keys 8*(row>>2) + 4*t + (row&3) (a row permutation of
 // the K fragment read, free of charge).
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -150,6 +151,7 @@ extern "C" int gram_enc_self_attn(const void* qkv, const float* bias, const uint
   if (P < 1 || H < 1 || L < 32 || L > GRAM_MAX_PASSAGE_LEN || (L & 31)) return GRAM_E_ARG;
   dim3 grid(H, P), block(256);
   hipStream_t st = (hipStream_t)stream;
+  gram_prof::Scope prof(GRAM_K_ENC_ATTN, st, 4.0 * P * H * L * L * 64);
   switch (L / 32) {
     case 1: hipLaunchKernelGGL(enc_attn_kernel<1>, grid, block, 0, st, (const bf16*)qkv, bias, mask, (bf16*)out, H); break;
     case 2: hipLaunchKernelGGL(enc_attn_kernel<2>, grid, block, 0, st, (const bf16*)qkv, bias, mask, (bf16*)out, H); break;

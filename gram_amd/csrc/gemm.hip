@@ -15,6 +15,7 @@
 // Global->LDS goes through registers (16 B per lane, issued a full k-tile ahead of its use),
 // one barrier per k-tile.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16* __restric
 template <int EPI>
 int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
   dim3 grid(N / BN, (M + BM - 1) / BM);
+  gram_prof::Scope prof(GRAM_K_GEMM, st, 2.0 * M * N * K);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI>),

@@ -1,6 +1,7 @@
 // rowops.hip -- HBM-bound row kernels: embedding gather, T5 RMSNorm (+late-fusion position
 // embedding / lm_head rescale fused), row log-sum-exp.  One wave per row, 16-byte accesses.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -88,12 +89,14 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
 
 extern "C" int gram_embed_i64(const float* table, const int64_t* ids, float* x, int rows, int d, void* stream) {
   if (rows < 1 || (d & 3)) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, 8.0 * rows * d);
   hipLaunchKernelGGL(embed_kernel<int64_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, x, rows, d);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int gram_embed_i32(const float* table, const int32_t* ids, float* x, int rows, int d, void* stream) {
   if (rows < 1 || (d & 3)) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, 8.0 * rows * d);
   hipLaunchKernelGGL(embed_kernel<int32_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, x, rows, d);
   GRAM_CHECK_LAUNCH();
   return 0;
@@ -105,6 +108,7 @@ extern "C" int gram_rmsnorm_bf16(const float* x, const float* w, void* out, int 
     N = 1;
     L = 1;
   }
+  gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, 6.0 * rows * d);
   hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)out, rows, d, eps,
                      scale, pos, N, L);
   GRAM_CHECK_LAUNCH();
@@ -112,6 +116,7 @@ extern "C" int gram_rmsnorm_bf16(const float* x, const float* w, void* out, int 
 }
 extern "C" int gram_row_lse(const float* logits, float* lse, int R, int V, void* stream) {
   if (R < 1 || (V & 3)) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_LSE, (hipStream_t)stream, 4.0 * R * V);
   hipLaunchKernelGGL(row_lse_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, lse, V);
   GRAM_CHECK_LAUNCH();
   return 0;

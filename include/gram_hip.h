@@ -214,6 +214,25 @@ int gram_generate(const gram_model_t* m, const int64_t* input_ids, const uint8_t
                   void* workspace, int64_t workspace_bytes, int64_t* sequences, float* scores,
                   int32_t* width_host, void* stream);
 
+/* ---- live per-kernel timing (bench.py) ------------------------------------------------ */
+enum gram_kernel_kind {
+  GRAM_K_GEMM = 0,          /* work = 2*M*N*K flops per launch                              */
+  GRAM_K_ENC_ATTN = 1,      /* work = 4*P*H*L*L*64 flops                                   */
+  GRAM_K_CROSS_ATTN = 2,    /* work = algorithmic HBM bytes: B*H*S*64*2(K,V)*2 B           */
+  GRAM_K_DEC_SELF_ATTN = 3, /* work = bytes of cached K/V read                              */
+  GRAM_K_ROWOPS = 4,        /* embed / rmsnorm: work = bytes moved                          */
+  GRAM_K_LSE = 5,           /* work = R*V*4 bytes                                          */
+  GRAM_K_BEAM = 6,          /* work = 0                                                    */
+  GRAM_K_COUNT = 7
+};
+/* Record a HIP-event pair around every launch of the selected kinds, on the launch stream.
+ * kind_mask = OR of (1 << kind); 0 disables and frees the pool.  Not thread-safe. */
+int gram_prof_enable(uint32_t kind_mask, int max_events);
+int gram_prof_reset(void);
+/* Sum of event-measured durations (ms), launch count and summed `work` for one kind; waits for
+ * the recorded events.  dropped = launches not recorded because the pool was full. */
+int gram_prof_collect(int kind, double* total_ms, int64_t* launches, double* work, int64_t* dropped);
+
 int gram_abi_version(void);
 
 #ifdef __cplusplus
