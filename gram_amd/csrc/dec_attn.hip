@@ -243,7 +243,7 @@ extern "C" int gram_cross_attn_decode(const void* q, const void* k_layer, const 
                                       int B, int K, int H, int S, void* stream) {
   if (B < 1 || K < 1 || K > GRAM_MAX_BEAMS || H < 1 || S < 32 || (S & 31)) return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  gram_prof::Scope prof(GRAM_K_CROSS_ATTN, st, 4.0 * B * H * S * 64 * 2);
+  gram_prof::Scope prof(GRAM_K_CROSS_ATTN, st, 4.0 * B * H * S * 64);  // K + V^T, bf16
   switch ((K + 15) / 16) {
     case 1: return launch_cross<1>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
     case 2: return launch_cross<2>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);

@@ -1,0 +1,157 @@
+"""Shared eval logic of the GRAM runners (the scoring half of src/runner/*_runner_gram.py).
+
+The training half of the reference runners (optimizer, schedulers, train_generator) is out of
+scope of this build; the constructor keeps the reference's argument list so that
+``get_runner(...)`` call sites (main_generative_gram.py:107-118,191-201) work unchanged.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from time import time
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ..utils import evaluate
+from ..utils import generation_trie as gt
+
+SPLIT_TOKENS = (1820, 9175)  # single_runner_gram.py:606-609 ("split token hard coded")
+
+
+def _arg(args, name, default):
+    return getattr(args, name, default) if args is not None else default
+
+
+class BaseRunner:
+    def __init__(self, model_rec, model_gen, tokenizer, train_loader_id, train_loader_rec, valid_loader, device, args):
+        self.model = model_rec
+        self.model_rec = model_rec
+        self.model_gen = model_gen  # unused by GRAM (single_runner_gram.py:44)
+        self.tokenizer = tokenizer
+        self.device = device
+        self.args = args
+        self.metrics = _arg(args, "metrics", "hit@5,hit@10,ndcg@5,ndcg@10").split(",")
+        # single_runner_gram.py:38-39: the beam is max(largest k in the metrics, --beam_size)
+        self.generate_num = max(max(int(m.split("@")[1]) for m in self.metrics), int(_arg(args, "beam_size", 1)))
+        self.length_penalty = float(_arg(args, "length_penalty", 1.0))
+        self.train_loader_id = train_loader_id
+        self.train_loader_rec = train_loader_rec
+        self.testloaders: List = []
+        self.validloaders: List = [valid_loader] if valid_loader is not None else []
+        self.cur_model_path = None
+        self.last_results = None
+
+    # ---------------------------------------------------------------- candidates -> Trie
+    def encode_candidates(self, candidates: Sequence) -> List[List[int]]:
+        """single_runner_gram.py:594-616.  Candidates that are already token-id sequences (the
+        offline fixtures: no tokenizer in this container) pass through."""
+        if len(candidates) and not isinstance(candidates[0], str):
+            return [list(map(int, c)) for c in candidates]
+        id_type = _arg(self.args, "item_id_type", "split")
+        out = []
+        for cand in candidates:
+            if id_type == "t5_token":
+                out.append([0] + self.tokenizer.convert_tokens_to_ids(cand.split(" ")) + [1])
+            elif id_type == "split":
+                out.append([0] + [t for t in self.tokenizer.encode(cand) if t not in SPLIT_TOKENS])
+            else:
+                out.append([0] + self.tokenizer.encode(f"{cand}"))
+        return out
+
+    def _decode(self, ids: torch.Tensor) -> List:
+        """batch_decode(skip_special_tokens=True) when a tokenizer exists, else id tuples with the
+        specials (pad 0, eos 1, -100 label padding) dropped -- the same equality relation whenever
+        decoding is injective on the candidate set."""
+        rows = ids.detach().cpu().tolist()
+        if self.tokenizer is not None:
+            rows = [[t for t in r if t >= 0] for r in rows]
+            return self.tokenizer.batch_decode(rows, skip_special_tokens=True)
+        return [tuple(t for t in r if t > 1) for r in rows]
+
+    def _load(self, path: Optional[str], strict: bool = True) -> None:
+        if path:
+            if os.path.isdir(path):
+                path = os.path.join(path, os.listdir(path)[0])
+            self.model.load_state_dict(torch.load(path, map_location=self.device, weights_only=True), strict=strict)
+
+    def _generate_model(self):
+        return self.model_rec.module if hasattr(self.model_rec, "module") else self.model_rec
+
+    def _score_loader(self, testloader):
+        """Per-user hit ranks for one loader: (ranks int16 [n], total generate() seconds, examples)."""
+        candidates = testloader.dataset.all_items
+        encoded = self.encode_candidates(candidates)
+        trie = gt.Trie(encoded)
+        fn = gt.prefix_allowed_tokens_fn(trie)
+        max_length = max(len(c) for c in encoded)  # single_runner_gram.py:633-636, hoisted out of the loop
+        K = self.generate_num
+        model = self._generate_model()
+        ranks, user_ids, examples, total_time = [], [], [], 0.0
+        rows_out = []
+        with torch.no_grad():
+            for batch in testloader:
+                input_ids = batch["item_text_ids"].to(self.device)
+                attention_mask = batch["item_text_masks"].to(self.device)
+                start = time()
+                pred = model.generate(
+                    input_ids=input_ids, attention_mask=attention_mask, max_length=max_length,
+                    prefix_allowed_tokens_fn=fn, num_beams=K, num_return_sequences=K, output_scores=True,
+                    return_dict_in_generate=True, length_penalty=self.length_penalty,
+                )
+                scores = pred["sequences_scores"].detach().cpu().numpy()
+                total_time += time() - start
+                gold = self._decode(batch["target_ids"])
+                gen = self._decode(pred["sequences"])
+                rel = evaluate.rel_results(gen, gold, scores, K)
+                ranks.append(evaluate.hit_ranks(rel))
+                user_ids += list(batch.get("user_ids", [None] * len(gold)))
+                for b in range(len(gold)):
+                    rows_out.append((gold[b], gen[b * K:(b + 1) * K], scores[b * K:(b + 1) * K]))
+                    if len(examples) < 10:
+                        examples.append(f"[GT] {gold[b]} || [top-1] {gen[b * K]}")
+        ranks = np.concatenate(ranks) if ranks else np.zeros(0, dtype=np.int16)
+        return ranks, total_time, examples, user_ids, rows_out
+
+    def _write_preds(self, fname, user_ids, ranks, rows_out):
+        """Preds TSV, single_runner_gram.py:580-588,675-694 (columns = all metrics, then gold,
+        '||'-joined predictions, '||'-joined scores)."""
+        K = self.generate_num
+        os.makedirs(os.path.dirname(fname), exist_ok=True)
+        with open(fname, "w") as f:
+            f.write("idx\t" + "\t".join(self.metrics) + "\tgold\tpred\tscores\n")
+            for uid, r, (gold, gen, sc) in zip(user_ids, ranks, rows_out):
+                per = evaluate.metrics_from_ranks([r], self.metrics, K)
+                f.write("\t".join([str(uid), "\t".join(str(x) for x in per), str(gold), "||".join(map(str, gen)),
+                                   "||".join(str(s) for s in sc)]) + "\n")
+
+    def test_from_model(self, rec_model_path=None, id_model_path=None):
+        self.model.eval()
+        self._load(rec_model_path, strict=False)
+        for loader in self.testloaders:
+            self.test_dataset_task(loader)
+
+    def test(self, path=None):
+        self.model.eval()
+        self._load(path)
+        for loader in self.testloaders:
+            self.test_dataset_task(loader)
+
+    def validate_from_model(self, rec_model_path=None, id_model_path=None):
+        self.model.eval()
+        self._load(rec_model_path, strict=False)
+        for loader in self.validloaders:
+            self.test_dataset_task(loader, mode="validation")
+
+    def validate(self, path=None):
+        self.model.eval()
+        self._load(path)
+        for loader in self.validloaders:
+            self.test_dataset_task(loader, mode="validation")
+
+    def train_generator(self):
+        raise NotImplementedError("training is outside the scoring path this build accelerates (SURVEY.md §8)")
+
+    def test_dataset_task(self, testloader, mode="test"):  # pragma: no cover - abstract
+        raise NotImplementedError

@@ -1,0 +1,107 @@
+"""CPU, world_size 2 (gloo): the data-parallel eval path -- users sharded across ranks, per-rank hit
+ranks combined by ONE all-gather, metric sums identical to the single-process run and to the
+reference's all_reduce(SUM) accounting (distributed_runner_gram.py:832-838).  The model is a stub
+whose generate() returns canned beams (the HIP model itself is covered by the -m gpu tests); what is
+under test is sharding, the collective, and the metric reconstruction."""
+import os
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gram_amd.runner import DistributedRunnerGRAM, SingleRunnerGRAM, shard_indices
+from gram_amd.utils import evaluate as ev
+
+K = 5
+N_USERS = 23  # not a multiple of the world size
+ITEMS = [[0, a, b, 1] for a in range(2, 8) for b in range(2, 8)]
+
+
+class StubModel(torch.nn.Module):
+    """generate(): user u (read from input_ids[b,0,0]) gets K distinct items in a seeded order."""
+
+    def forward(self, *a, **k):
+        raise NotImplementedError
+
+    def generate(self, input_ids, attention_mask, max_length, num_beams, **kw):
+        seqs, scores = [], []
+        for u in input_ids[:, 0, 0].tolist():
+            g = torch.Generator().manual_seed(1000 + u)
+            pick = torch.randperm(len(ITEMS), generator=g)[:num_beams].tolist()
+            seqs += [ITEMS[i] for i in pick]
+            scores += sorted((-torch.rand(num_beams, generator=g)).tolist(), reverse=True)
+        return {"sequences": torch.tensor(seqs), "sequences_scores": torch.tensor(scores)}
+
+
+def _gold(u):
+    g = torch.Generator().manual_seed(1000 + u)
+    pick = torch.randperm(len(ITEMS), generator=g)[:K].tolist()
+    # gold sits at rank u % (K+2); ranks >= K mean "not retrieved"
+    r = u % (K + 2)
+    return ITEMS[pick[r]] if r < K else ITEMS[(pick[0] + 17) % len(ITEMS)] if ITEMS[(pick[0] + 17) % len(ITEMS)] not in [ITEMS[i] for i in pick] else [0, 9, 9, 1]
+
+
+class Loader(list):
+    def __init__(self, users, bs=4):
+        batches = []
+        for i in range(0, len(users), bs):
+            us = users[i:i + bs]
+            ids = torch.zeros(len(us), 2, 8, dtype=torch.long)
+            ids[:, 0, 0] = torch.tensor(us)
+            tgt = torch.full((len(us), 6), -100)
+            for j, u in enumerate(us):
+                gseq = _gold(u)[1:]
+                tgt[j, : len(gseq)] = torch.tensor(gseq)
+            batches.append({"item_text_ids": ids, "item_text_masks": torch.ones_like(ids, dtype=torch.bool), "target_ids": tgt,
+                            "user_ids": [f"u{u}" for u in us]})
+        super().__init__(batches)
+        self.dataset = SimpleNamespace(all_items=ITEMS, dataset="Synthetic", task="sequential")
+
+
+ARGS = SimpleNamespace(metrics="hit@1,hit@5,ndcg@3,ndcg@5", beam_size=K, length_penalty=1.0, item_id_type="split", save_predictions=False)
+
+
+def _single():
+    r = SingleRunnerGRAM(StubModel(), None, None, None, None, None, "cpu", ARGS)
+    r.test_dataset_task(Loader(list(range(N_USERS))))
+    return r.last_results
+
+
+def _worker(rank, world, path, pad, q):
+    dist.init_process_group("gloo", init_method=f"file://{path}", rank=rank, world_size=world)
+    try:
+        r = DistributedRunnerGRAM(StubModel(), None, None, None, None, None, "cpu", ARGS, rank)
+        r.test_dataset_task(Loader(shard_indices(N_USERS, world, rank, pad_like_reference=pad)))
+        q.put((rank, r.last_results["sums"].tolist(), r.last_results["total"], sorted(r.last_results["hit_ranks"].tolist())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pad", [False, True])
+def test_world2_allgather_matches_single_process(pad):
+    single = _single()
+    assert single["total"] == N_USERS
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_worker, args=(r, 2, os.path.join(d, "rdzv"), pad, q)) for r in range(2)]
+        [p.start() for p in procs]
+        res = [q.get(timeout=120) for _ in procs]
+        [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (r0, s0, t0, h0), (r1, s1, t1, h1) = sorted(res)
+    assert s0 == s1 and t0 == t1 and h0 == h1  # every rank reconstructs the same global result
+    if not pad:
+        assert t0 == N_USERS
+        assert np.allclose(s0, single["sums"])
+        assert h0 == sorted(single["hit_ranks"].tolist())
+    else:
+        # DistributedSampler accounting: ceil(n/W)*W samples, the padded duplicate is counted twice
+        assert t0 == 24
+        dup = shard_indices(N_USERS, 2, 0, True) + shard_indices(N_USERS, 2, 1, True)
+        ranks = np.array([single["hit_ranks"][u] for u in dup])
+        assert np.allclose(s0, ev.metrics_from_ranks(ranks, ARGS.metrics.split(","), K))

@@ -1,0 +1,122 @@
+"""CPU: host-side mirrors of the reference interface (Trie / FlatTrie, metrics, model wrapper,
+runner factory, sharding) against the oracle and the golden vectors."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import gram_amd
+from gram_amd.model.gram import relative_position_bucket
+from gram_amd.runner import get_runner, shard_indices
+from gram_amd.utils import evaluate as ev
+from gram_amd.utils import generation_trie as gt
+from oracle import gram_oracle as O
+
+
+def _rand_seqs(rng, n, lo, hi, vocab):
+    return [[0] + [rng.randrange(2, vocab) for _ in range(rng.randrange(lo, hi + 1))] + [1] for _ in range(n)]
+
+
+def test_trie_mirror_matches_oracle_and_flat_form():
+    rng = random.Random(3)
+    seqs = _rand_seqs(rng, 300, 1, 5, 12)
+    a, b = gt.Trie(seqs), O.Trie(seqs)
+    flat = gt.FlatTrie(a)
+    assert len(a) == len(b) == 300
+    probes = [[]] + [s[:k] for s in seqs[:80] for k in range(1, len(s) + 1)] + [[0, 99], [5], [0, 2, 2, 2, 2, 2, 2, 2]]
+    for p in probes:
+        assert sorted(a.get(p)) == sorted(b.get(p)) == flat.get(p), p
+    fn = gt.prefix_allowed_tokens_fn(a)
+    assert sorted(fn(0, torch.tensor([0]))) == sorted(b.get([0]))
+    assert sorted(map(tuple, a)) == sorted({tuple(s) for s in seqs})
+    assert gt.Trie.load_from_dict(a.trie_dict).len == len({tuple(s) for s in seqs})
+    assert a[[0]] == a.get([0])
+    assert gt.exact_match(["a", "b", "c", "d"], ["b", "x"], 2) == 1
+    # CSR invariants
+    assert flat.child_off[0] == 0 and flat.child_off[-1] == flat.n_edges == len(flat.child_tok)
+    for n in range(flat.n_nodes):
+        toks = flat.child_tok[flat.child_off[n]:flat.child_off[n + 1]]
+        assert np.all(np.diff(toks) > 0)
+
+
+def test_trie_golden_and_real_shapes(golden_dir):
+    z = np.load(os.path.join(golden_dir, "ref_tiny.npz"))
+    unpad = lambda rows: [[int(x) for x in r if x >= 0] for r in rows]
+    t = gt.Trie(unpad(z["trie_cands"]))
+    flat = gt.FlatTrie(t)
+    for probe, ans in zip(unpad(z["trie_probes"]), unpad(z["trie_answers"])):
+        assert sorted(t.get(probe)) == ans == flat.get(probe)
+    tries = np.load(os.path.join(golden_dir, "tries.npz"))
+    # node counts / fan-outs recorded in SURVEY.md §8 A11 (incl. EOS leaves and the start token)
+    expect = {"Beauty": (12101, 255, 108), "Toys": (11924, 186, 30), "Sports": (18357, 175, 28), "Yelp": (20033, 263, 21)}
+    for ds, (n_items, fan, root_fan) in expect.items():
+        cands = unpad(tries[f"{ds}_cands"])
+        f = gt.FlatTrie(gt.Trie(cands))
+        assert f.n_sequences == n_items and f.max_fanout == fan and len(f.get([0])) == root_fan, ds
+
+
+def test_metrics_mirror(golden_dir):
+    z = np.load(os.path.join(golden_dir, "ref_tiny.npz"))
+    rel = ev.rel_results(["a", "b", "c", "d"], ["c"], [-1.0, -3.0, -2.0, -4.0], 4)
+    assert rel == z["rel_known"].tolist()
+    assert np.array_equal(ev.get_metrics_results(rel, ["hit@1", "hit@2", "ndcg@2", "ndcg@4"]), z["met_known"])
+    k = int(z["rand_k"])
+    rel = ev.rel_results(z["rand_preds"].tolist(), z["rand_golds"].tolist(), z["rand_scores"].tolist(), k)
+    assert rel == z["rel_rand"].tolist()
+    mets = z["rand_metrics"].tolist()
+    assert np.array_equal(ev.get_metrics_results(rel, mets), z["met_rand"])
+    # compact hit-rank form used by the DP runner reproduces the sums when predictions are unique
+    uniq = ev.rel_results(["a", "b", "c", "x", "y", "z"], ["c", "q"], [3, 2, 1, 3, 2, 1], 3)
+    ranks = ev.hit_ranks(uniq)
+    assert ranks.tolist() == [2, -1]
+    assert np.array_equal(ev.metrics_from_ranks(ranks, ["hit@1", "hit@3", "ndcg@3"], 3), ev.get_metrics_results(uniq, ["hit@1", "hit@3", "ndcg@3"]))
+
+
+def test_model_wrapper_contract():
+    oc = O.OracleConfig(vocab_size=256, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2, max_item_num=5)
+    cfg = gram_amd.T5Config(vocab_size=256, d_model=128, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2, max_item_num=5)
+    m = gram_amd.create_model("gram", config=cfg)
+    sd = O.init_state_dict(oc, 1)
+    assert set(m.state_dict()) == set(sd)  # the reference checkpoint key layout
+    m.load_state_dict(sd)
+    assert torch.equal(m.state_dict()["lm_head.weight"], sd["shared.weight"])
+    assert m.state_dict()["encoder.position_embedding.weight"].data_ptr() == m.state_dict()["position_embedding.weight"].data_ptr()
+    # load_t5: plain T5 key layout, non-strict, position embedding untouched
+    t5 = {k.replace("encoder.encoder.block.", "encoder.block.").replace(".module.", ".").replace("encoder.encoder.", "encoder."): v + 1
+          for k, v in sd.items() if "position_embedding" not in k}
+    pos_before = m.state_dict()["position_embedding.weight"].clone()
+    m.load_t5(t5)
+    assert torch.equal(m.state_dict()["encoder.encoder.block.1.module.layer.1.DenseReluDense.wi.weight"],
+                       sd["encoder.encoder.block.1.module.layer.1.DenseReluDense.wi.weight"] + 1)
+    assert torch.equal(m.state_dict()["position_embedding.weight"], pos_before)
+    with pytest.raises(ValueError):
+        gram_amd.create_model("p5", config=cfg)
+    with pytest.raises(ValueError):
+        get_runner("multi", m, None, None, None, None, None, "cpu", None)
+    # no CPU fallback: generate on a CPU model fails loudly
+    fn = gt.prefix_allowed_tokens_fn(gt.Trie([[0, 2, 1]]))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.generate(torch.zeros(1, 1, 32, dtype=torch.long), torch.ones(1, 1, 32, dtype=torch.bool), 3, prefix_allowed_tokens_fn=fn, num_beams=1)
+    with pytest.raises(NotImplementedError):
+        m(input_ids=torch.zeros(1, 1, 32, dtype=torch.long))
+
+
+def test_relative_bucket_tables_match_oracle():
+    rel = torch.arange(-127, 128)
+    assert torch.equal(relative_position_bucket(rel, True, 32, 128), O.relative_position_bucket(rel, True, 32, 128))
+    d = -torch.arange(0, 32)
+    assert torch.equal(relative_position_bucket(d, False, 32, 128), O.relative_position_bucket(d, False, 32, 128))
+
+
+def test_shard_indices_vs_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    n, W = 23, 4
+    data = list(range(n))
+    seen = []
+    for r in range(W):
+        ref = list(DistributedSampler(data, num_replicas=W, rank=r))  # shuffle=True, seed=0 (distributed_runner_gram.py:351)
+        assert shard_indices(n, W, r, pad_like_reference=True) == ref == O.distributed_sampler_indices(n, W, r)
+        seen += shard_indices(n, W, r)
+    assert sorted(seen) == data  # default sharding: every user exactly once
