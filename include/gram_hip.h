@@ -233,6 +233,10 @@ int gram_prof_reset(void);
  * the recorded events.  dropped = launches not recorded because the pool was full. */
 int gram_prof_collect(int kind, double* total_ms, int64_t* launches, double* work, int64_t* dropped);
 
+/* Tuning hook: force a GEMM staging variant (0 = register-staged double buffer, 1 = LDS-DMA
+ * single buffer, -1 = automatic per problem size).  Used by tests/bench_gemm.py. */
+int gram_debug_set_gemm_variant(int variant);
+
 int gram_abi_version(void);
 
 #ifdef __cplusplus

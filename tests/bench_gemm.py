@@ -1,0 +1,61 @@
+"""GPU micro-benchmark (not a test): gram_gemm_bf16 variants on the shapes of the scoring path.
+    python tests/bench_gemm.py [--batch 128]
+Checks each variant against torch on a sampled block, then times it with HIP events."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gram_amd import _lib  # noqa: E402
+from tests import gpu_util as G  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--variants", default="0,1")
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    lib = _lib.load()
+    Me, Md = a.batch * 384, a.batch * 20
+    shapes = [("enc qkv", Me, 2304, 768, _lib.EPI_BF16), ("enc o", Me, 768, 768, _lib.EPI_F32_ADD),
+              ("enc wi", Me, 3072, 768, _lib.EPI_BF16_RELU), ("enc wo", Me, 768, 3072, _lib.EPI_F32_ADD),
+              ("dec qkv", Md, 2304, 768, _lib.EPI_BF16), ("dec o/q", Md, 768, 768, _lib.EPI_F32_ADD),
+              ("dec wi", Md, 3072, 768, _lib.EPI_BF16_RELU), ("dec wo", Md, 768, 3072, _lib.EPI_F32_ADD),
+              ("lm_head", Md, 32128, 768, _lib.EPI_F32)]
+    g = torch.Generator().manual_seed(0)
+    for name, M, N, K, epi in shapes:
+        A = (torch.randn(M, K, generator=g)).to(G.DEV).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).to(G.DEV).to(torch.bfloat16)
+        f32 = epi in (_lib.EPI_F32_ADD, _lib.EPI_F32)
+        C = torch.zeros(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device=G.DEV)
+        ref = (A[:256].float() @ W.float().T)
+        if epi == _lib.EPI_BF16_RELU:
+            ref = ref.clamp(min=0)
+        line = f"{name:8s} M={M:6d} N={N:5d} K={K:4d}"
+        for v in [int(x) for x in a.variants.split(",")]:
+            lib.gram_debug_set_gemm_variant(v)
+            C.zero_()
+            G.gemm(A, W, epi, C)
+            torch.cuda.synchronize()
+            err = (C[:256].float() - ref).abs().max().item()
+            ok = err < (2e-3 if f32 else 3e-2)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                G.gemm(A, W, epi, C)
+            s.record()
+            for _ in range(a.iters):
+                G.gemm(A, W, epi, C)
+            e.record()
+            torch.cuda.synchronize()
+            us = s.elapsed_time(e) * 1e3 / a.iters
+            line += f" | v{v}: {us:8.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF {'ok' if ok else 'BAD err=%.3g' % err}"
+        print(line, flush=True)
+        del A, W, C
+    lib.gram_debug_set_gemm_variant(-1)
+
+
+if __name__ == "__main__":
+    main()
