@@ -32,7 +32,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
-enum { V_REG2 = 0, V_DMA = 1 };
+enum { V_REG2 = 0, V_DMA = 1, V_DMA2 = 2, V_DMA_M256 = 3, V_DMA2_M256 = 4, V_DMA2_256SQ = 5, V_DMA_256SQ = 6, V_RING = 7, V_IL = 8 };
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -57,64 +57,90 @@ __device__ __forceinline__ void tile_of_block(int ntn, int& mt, int& nt) {
 }
 
 // one k-tile of MFMAs from a staged LDS tile pair
-__device__ __forceinline__ void compute_tile(const char* sa, const char* sw, int wm, int wn, int r16, int g, f32x4 (&acc)[4][4]) {
+template <int TNW>
+__device__ __forceinline__ void compute_tile(const char* sa, const char* sw, int wm, int wn, int r16, int g,
+                                             f32x4 (&acc)[TNW][4]) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 fw[4], fa[4];
+    bf16x8 fw[TNW], fa[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fw[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + r16, ks * 4 + g));
-      fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + r16, ks * 4 + g));
-    }
+    for (int i = 0; i < TNW; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 16 * TNW + i * 16 + r16, ks * 4 + g));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + r16, ks * 4 + g));
+#pragma unroll
+    for (int i = 0; i < TNW; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
   }
 }
 
-// acc[i][j] lane (r16,g) element e = C[m = m0+wm*64+j*16+r16][n = n0+wn*64+i*16+4g+e]
-template <int EPI>
-__device__ __forceinline__ void epilogue(f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int r16, int g, int M,
+// acc[i][j] lane (r16,g) element e = C[m = m0+wm*64+j*16+r16][n = n0+wn*16*TNW+i*16+4g+e]
+//
+// bf16 outputs: a lane owns 4 consecutive columns (8 B) of two adjacent n-tiles; lanes g and g^1
+// swap halves (one cross-lane exchange per tile pair) so that every lane issues ONE 16-byte store
+// per tile pair instead of two 8-byte ones -- the store tail of these K=768 GEMMs is issue-bound.
+__device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+  return __builtin_bit_cast(uint2, o);
+}
+
+template <int EPI, int TNW>
+__device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, int wm, int wn, int r16, int g, int M,
                                          const EpiArgs& ep) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + wm * 64 + j * 16 + r16;
-    if (m >= M) continue;
+    const bool row_ok = m < M;
+    if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = n0 + wn * 64 + i * 16 + 4 * g;
-      f32x4 v = acc[i][j];
-      if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
+      for (int i = 0; i < TNW; i += 2) {
+        f32x4 v0 = acc[i][j], v1 = acc[i + 1][j];
         if constexpr (EPI == GRAM_EPI_BF16_RELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) {
+            v0[e] = fmaxf(v0[e], 0.f);
+            v1[e] = fmaxf(v1[e], 0.f);
+          }
         }
-        bf16x4 o;
+        const uint2 lo = pack_bf16x4(v0), hi = pack_bf16x4(v1);
+        const bool odd = g & 1;
+        const uint2 send = odd ? lo : hi;
+        uint2 recv;
+        recv.x = __shfl_xor(send.x, 16, 64);
+        recv.y = __shfl_xor(send.y, 16, 64);
+        // even g: tile i, columns 8*(g/2)..+7 = [own lo | partner's lo]; odd g: tile i+1 = [partner's hi | own hi]
+        const uint4 out = odd ? make_uint4(recv.x, recv.y, hi.x, hi.y) : make_uint4(lo.x, lo.y, recv.x, recv.y);
+        const int n = n0 + wn * 16 * TNW + (i + (odd ? 1 : 0)) * 16 + 8 * (g >> 1);
+        if (row_ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + n) = out;
+      }
+    } else {
+      if (!row_ok) continue;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + n) = o;
-      } else if constexpr (EPI == GRAM_EPI_F32_ADD) {
-        f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n);
-        f32x4 old = *p;
-        *p = old + v;
-      } else if constexpr (EPI == GRAM_EPI_F32) {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n) = v;
-      } else {  // GRAM_EPI_KV_BANK
-        const int b = m / ep.S, s = m - b * ep.S;
-        const int lw = n / ep.inner;  // layer*2 + which   (uniform per block: inner % 128 == 0)
-        const int layer = lw >> 1, which = lw & 1;
-        const int rem = n - lw * ep.inner;
-        const int h = rem >> 6, d = rem & 63;
-        const size_t head = ((size_t)layer * ep.B + b) * ep.H + h;
-        if (which == 0) {
-          bf16x4 o;
+      for (int i = 0; i < TNW; ++i) {
+        const int n = n0 + wn * 16 * TNW + i * 16 + 4 * g;
+        f32x4 v = acc[i][j];
+        if constexpr (EPI == GRAM_EPI_F32_ADD) {
+          f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n);
+          f32x4 old = *p;
+          *p = old + v;
+        } else if constexpr (EPI == GRAM_EPI_F32) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n) = v;
+        } else {  // GRAM_EPI_KV_BANK
+          const int b = m / ep.S, s = m - b * ep.S;
+          const int lw = n / ep.inner;  // layer*2 + which   (uniform per block: inner % 128 == 0)
+          const int layer = lw >> 1, which = lw & 1;
+          const int rem = n - lw * ep.inner;
+          const int h = rem >> 6, d = rem & 63;
+          const size_t head = ((size_t)layer * ep.B + b) * ep.H + h;
+          if (which == 0) {
+            const uint2 o = pack_bf16x4(v);
+            *reinterpret_cast<uint2*>(ep.bank_k + (head * ep.S + s) * 64 + d) = o;
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-          *reinterpret_cast<bf16x4*>(ep.bank_k + (head * ep.S + s) * 64 + d) = o;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ep.bank_vt[(head * 64 + d + e) * ep.S + s] = (bf16)v[e];
+            for (int e = 0; e < 4; ++e) ep.bank_vt[(head * 64 + d + e) * ep.S + s] = (bf16)v[e];
+          }
         }
       }
     }
@@ -179,91 +205,355 @@ __global__ __launch_bounds__(256, 2) void gemm_reg2_kernel(const bf16* __restric
     const int stage = kt & 1;
     if (kt + 1 < nkt) load_tile(kt + 1);
     const char* sa = smem + stage * 2 * TILE_BYTES;
-    compute_tile(sa, sa + TILE_BYTES, wm, wn, r16, g, acc);
+    compute_tile<4>(sa, sa + TILE_BYTES, wm, wn, r16, g, acc);
     if (kt + 1 < nkt) store_tile(stage ^ 1);
     __syncthreads();
   }
-  epilogue<EPI>(acc, m0, n0, wm, wn, r16, g, M, ep);
+  epilogue<EPI, 4>(acc, m0, n0, wm, wn, r16, g, M, ep);
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(256, 4) void gemm_dma_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M,
-                                                          int N, int K, int lda, EpiArgs ep) {
+template <int EPI, int WM, int NST, int TNW>
+__global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void gemm_dma_kernel(
+    const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, int lda, EpiArgs ep) {
+  // WM x 2 waves, block tile (64*WM) x 128.  NST = 1: single LDS stage, latency hidden by the other
+  // resident workgroups.  NST = 2: the DMA of k-tile kt+1 is issued before the MFMAs of k-tile kt and
+  // drained by the (single) barrier after them.
+  constexpr int TBM = 64 * WM, TBN = 32 * TNW;
+  constexpr int A_BYTES = TBM * BK * 2, W_BYTES = TBN * BK * 2, STAGE = A_BYTES + W_BYTES;
+  constexpr int NW = 2 * WM;                       // waves per workgroup
+  constexpr int AG = (TBM / 8) / NW, WG = (TBN / 8) / NW;  // 8-row DMA groups per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int mt, nt;
-  tile_of_block(N / BN, mt, nt);
-  const int m0 = mt * BM, n0 = nt * BN;
+  tile_of_block(N / TBN, mt, nt);
+  const int m0 = mt * TBM, n0 = nt * TBN;
   const int r16 = lane & 15, g = lane >> 4;
 
-  // LDS-DMA map: a wave instruction fills one 8-row x 128-B group (1 KiB, lane-linear);
-  // wave w owns groups 4w..4w+3 of both operands.  Lane l lands at (row 8*grp + l>>3, slot l&7),
-  // so it must FETCH chunk (l&7) ^ ((row>>1)&7) for the read-side swizzle to find it.
-  const bf16* a_src[4];
-  const bf16* w_src[4];
+  // LDS-DMA map: a wave instruction fills one 8-row x 128-B group (1 KiB, lane-linear).
+  // Lane l lands at (row 8*grp + l>>3, slot l&7), so it must FETCH chunk (l&7) ^ ((row>>1)&7)
+  // for the read-side swizzle to find it.
+  const bf16* a_src[AG];
+  const bf16* w_src[WG];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int grp = wave * 4 + i;
-    const int row = grp * 8 + (lane >> 3);
+  for (int i = 0; i < AG; ++i) {
+    const int row = (wave * AG + i) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     const int am = min(m0 + row, M - 1);  // rows past M: any valid address (never stored)
     a_src[i] = A + (size_t)am * lda + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < WG; ++i) {
+    const int row = (wave * WG + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     w_src[i] = W + (size_t)(n0 + row) * K + chunk * 8;
   }
-  char* sa = smem;
-  char* sw = smem + TILE_BYTES;
-
-  f32x4 acc[4][4];
+  auto dma = [&](int kt, int stage) {
+    char* sa = smem + stage * STAGE;
+    char* sw = sa + A_BYTES;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < AG; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sa + (wave * AG + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WG; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sw + (wave * WG + i) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[TNW][4];
+#pragma unroll
+  for (int i = 0; i < TNW; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nkt = K / BK;
-  for (int kt = 0; kt < nkt; ++kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int grp = wave * 4 + i;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sa + grp * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sw + grp * 1024), 16, 0, 0);
+  if constexpr (NST == 1) {
+    for (int kt = 0; kt < nkt; ++kt) {
+      dma(kt, 0);
+      __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+      compute_tile<TNW>(smem, smem + A_BYTES, wm, wn, r16, g, acc);
+      __syncthreads();
     }
-    __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
-    compute_tile(sa, sw, wm, wn, r16, g, acc);
+  } else {
+    dma(0, 0);
     __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int st = kt & 1;
+      if (kt + 1 < nkt) dma(kt + 1, st ^ 1);
+      compute_tile<TNW>(smem + st * STAGE, smem + st * STAGE + A_BYTES, wm, wn, r16, g, acc);
+      __syncthreads();  // drains DMA(kt+1) and fences the reads of stage st
+    }
   }
-  epilogue<EPI>(acc, m0, n0, wm, wn, r16, g, M, ep);
+  epilogue<EPI, TNW>(acc, m0, n0, wm, wn, r16, g, M, ep);
 }
 
-int pick_variant(int M, int N) {
+// ---------------------------------------------------------------------------------------------
+// V_RING: 256x256 tile, 8 waves (4 x 2, wave tile 64 x 128), k-stages of 32 in a 4-slot LDS ring
+// (4 x 32 KiB = 128 KiB): three stages (96 KiB) are always in flight while the fourth is consumed.
+// Counter profiles of the simpler variants showed the MFMA pipe ~37 % busy, zero bank conflicts,
+// and an L2->LDS fill rate pinned at bytes-in-flight / DMA latency; this variant raises the bytes
+// in flight per CU instead of the occupancy.  DMA completion is tracked with COUNTED s_waitcnt
+// vmcnt(N) (each wave issues exactly 4 DMA instructions per stage) and a raw s_barrier, so the
+// prefetch stays in flight across the barrier (__syncthreads() would drain it).
+// Stage tiles are [256 rows][32 k] bf16 = 64-B rows; 16-B chunk swizzle chunk ^= F[(row>>2)&3],
+// F = {0,2,3,1}, conflict-free for the ds_read_b128 lane groups (derivation in DESIGN.md).
+__device__ __forceinline__ int fsw(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+__device__ __forceinline__ int swz32(int row, int chunk) { return row * 64 + ((chunk ^ fsw(row)) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
+                                                           int K, int lda, EpiArgs ep) {
+  constexpr int TB = 256, SK = 32, OPB = TB * SK * 2 /*16 KiB*/, STAGE = 2 * OPB, NSLOT = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int mt, nt;
+  tile_of_block(N / TB, mt, nt);
+  const int m0 = mt * TB, n0 = nt * TB;
+  const int r16 = lane & 15, g = lane >> 4;
+
+  // DMA map: one wave instruction = 16 rows x 64 B (1 KiB, lane-linear): lane l -> row 16*grp + (l>>2),
+  // slot l&3, fetching chunk slot ^ F.  Each operand stage is 16 groups; wave w owns groups 2w, 2w+1.
+  const bf16* a_src[2];
+  const bf16* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave * 2 + i) * 16 + (lane >> 2);
+    const int chunk = (lane & 3) ^ fsw(row);
+    a_src[i] = A + (size_t)min(m0 + row, M - 1) * lda + chunk * 8;
+    w_src[i] = W + (size_t)(n0 + row) * K + chunk * 8;
+  }
+  auto dma = [&](int kt) {
+    char* sa = smem + (kt & (NSLOT - 1)) * STAGE;
+    char* sw = sa + OPB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * SK),
+                                       (__attribute__((address_space(3))) void*)(sa + (wave * 2 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + kt * SK),
+                                       (__attribute__((address_space(3))) void*)(sw + (wave * 2 + i) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / SK;
+  dma(0);
+  if (nk > 1) dma(1);
+  if (nk > 2) dma(2);
+  for (int kt = 0; kt < nk; ++kt) {
+    // retire this wave's share of stage kt, leaving the younger stages in flight
+    const int ahead = min(2, nk - 1 - kt);
+    if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // stage kt complete for every wave; slot (kt-1)&3 no longer read
+    if (kt + 3 < nk) dma(kt + 3);
+    const char* sa = smem + (kt & (NSLOT - 1)) * STAGE;
+    const char* sw = sa + OPB;
+    bf16x8 fw[8], fa[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(sw + swz32(wn * 128 + i * 16 + r16, g));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz32(wm * 64 + i * 16 + r16, g));
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
+  }
+  epilogue<EPI, 8>(acc, m0, n0, wm, wn, r16, g, M, ep);
+}
+
+template <int EPI>
+int launch_ring(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+  constexpr int smem = 4 * 2 * 256 * 32 * 2;  // 128 KiB
+  if (N % 256 || K % 32) return GRAM_E_ARG;
+  const int nblocks = (N / 256) * ((M + 255) / 256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_ring_kernel<EPI>, dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// V_IL: the 256x256 double-buffered DMA variant with the next k-tile's 8 DMA instructions
+// INTERLEAVED between MFMA groups (one DMA after every 8 MFMAs) instead of issued back-to-back
+// after the barrier: an LDS-DMA instruction costs ~100+ issue cycles inside a busy phase, and in the
+// plain variant all 8 waves pay 8 of them at the same moment while the MFMA pipe idles.
+template <int EPI, int ABL = 0>  // ABL (ablation, microbench only): 1 = DMA only, 2 = MFMA only
+__global__ __launch_bounds__(512, 2) void gemm_il_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
+                                                         int K, int lda, EpiArgs ep) {
+  constexpr int TB = 256, OPB = TB * BK * 2 /*32 KiB*/, STAGE = 2 * OPB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int mt, nt;
+  tile_of_block(N / TB, mt, nt);
+  const int m0 = mt * TB, n0 = nt * TB;
+  const int r16 = lane & 15, g = lane >> 4;
+
+  const bf16* src[8];  // pieces 0-3: A groups 4w..4w+3, pieces 4-7: W groups 4w..4w+3
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    src[i] = A + (size_t)min(m0 + row, M - 1) * lda + chunk * 8;
+    src[4 + i] = W + (size_t)(n0 + row) * K + chunk * 8;
+  }
+  auto dma_piece = [&](int kt, int stage, int p) {
+    char* dst = smem + stage * STAGE + (p >= 4 ? OPB : 0) + (wave * 4 + (p & 3)) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[p] + kt * BK),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K / BK;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) dma_piece(0, 0, p);
+  __syncthreads();
+  // fragment registers are double-buffered: the ds_reads of k-step (ks+1) are issued before the
+  // MFMAs of k-step ks, so the LDS latency is exposed once per k-tile (after the barrier) only
+  bf16x8 fw0[8], fa0[4], fw1[8], fa1[4];
+  auto ldfrag = [&](bf16x8 (&fw)[8], bf16x8 (&fa)[4], const char* sa, const char* sw, int ks) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 128 + i * 16 + r16, ks * 4 + g));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + r16, ks * 4 + g));
+  };
+  auto mma = [&](bf16x8 (&fw)[8], bf16x8 (&fa)[4], int kt, int st, int ks, bool more) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (ABL != 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
+      }
+      if ((i & 1) == 1) {
+        if (more && ABL != 2) dma_piece(kt + 1, st ^ 1, ks * 4 + (i >> 1));
+        __builtin_amdgcn_sched_barrier(0);  // keep the DMA between these MFMA groups
+      }
+    }
+  };
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int st = kt & 1;
+    const bool more = kt + 1 < nkt;
+    const char* sa = smem + st * STAGE;
+    const char* sw = sa + OPB;
+    ldfrag(fw0, fa0, sa, sw, 0);
+    ldfrag(fw1, fa1, sa, sw, 1);
+    mma(fw0, fa0, kt, st, 0, more);
+    mma(fw1, fa1, kt, st, 1, more);
+    __syncthreads();  // drains DMA(kt+1), fences the reads of stage st
+  }
+  if constexpr (ABL == 3) {  // ablation: no stores (keep acc live)
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (keep == 123.456f) reinterpret_cast<float*>(ep.C)[0] = keep;
+  } else {
+    epilogue<EPI, 8>(acc, m0, n0, wm, wn, r16, g, M, ep);
+  }
+}
+
+template <int EPI, int ABL = 0>
+int launch_il(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+  constexpr int smem = 2 * 2 * 256 * 64 * 2;  // 128 KiB
+  if (N % 256) return GRAM_E_ARG;
+  const int nblocks = (N / 256) * ((M + 255) / 256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_il_kernel<EPI, ABL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_il_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+// Measured on MI355X (tests/bench_gemm.py, B = 512 shapes; TFLOP/s):
+//   M >= 32768 (encoder):  N=768,K=3072  V_IL 920 > V_DMA_M256 883 > V_DMA 829
+//                          other shapes  V_DMA_M256 871-883 >= V_IL 855-863 > V_DMA 806-823
+//   lm_head (N=32128):     V_DMA_M256 783 > V_DMA 614
+//   M ~ 10240 (decoder):   V_DMA 475-832 > V_DMA_M256 418-801 > V_IL 299-696
+int pick_variant(int M, int N, int K) {
   if (g_force_variant >= 0) return g_force_variant;
-  (void)M;
-  (void)N;
-  return V_DMA;  // measured faster on every shape of the path, small grids included (tests/bench_gemm.py)
+  const long tiles256 = (long)((M + 255) / 256) * (N / BN);
+  if (tiles256 >= 2048) {  // >= 8 workgroups of 256x128 per CU: the big-tile variants pay off
+    if (N % 256 == 0 && K >= 2048 && M >= 32768) return V_IL;
+    return V_DMA_M256;
+  }
+  return V_DMA;
+}
+
+template <int EPI, int WM, int NST, int TNW = 4>
+int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+  constexpr int TBM = 64 * WM, TBN = 32 * TNW;
+  constexpr int smem = NST * (TBM + TBN) * BK * 2;
+  if (N % TBN) return GRAM_E_ARG;
+  const int nblocks = (N / TBN) * ((M + TBM - 1) / TBM);
+  static bool attr_set = false;
+  if (!attr_set && smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<EPI, WM, NST, TNW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_dma_kernel<EPI, WM, NST, TNW>), dim3(nblocks), dim3(WM * 128), smem, st, (const bf16*)A, (const bf16*)W,
+                     M, N, K, lda, ep);
+  GRAM_CHECK_LAUNCH();
+  return 0;
 }
 
 template <int EPI>
 int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
-  const int nblocks = (N / BN) * ((M + BM - 1) / BM);
   gram_prof::Scope prof(GRAM_K_GEMM, st, 2.0 * M * N * K);
-  if (pick_variant(M, N) == V_DMA) {
-    hipLaunchKernelGGL(gemm_dma_kernel<EPI>, dim3(nblocks), dim3(256), 2 * TILE_BYTES, st, (const bf16*)A, (const bf16*)W, M, N,
-                       K, lda, ep);
-  } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_reg2_kernel<EPI>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_reg2_kernel<EPI>, dim3(nblocks), dim3(256), 4 * TILE_BYTES, st, (const bf16*)A, (const bf16*)W, M,
-                       N, K, lda, ep);
+  switch (pick_variant(M, N, K)) {
+    case V_DMA: return launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st);
+    case V_DMA2: return launch_dma<EPI, 2, 2>(A, W, M, N, K, lda, ep, st);
+    case V_DMA_M256: return launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, st);
+    case V_DMA2_M256: return launch_dma<EPI, 4, 2>(A, W, M, N, K, lda, ep, st);
+    case V_DMA2_256SQ: return launch_dma<EPI, 4, 2, 8>(A, W, M, N, K, lda, ep, st);
+    case V_DMA_256SQ: return launch_dma<EPI, 4, 1, 8>(A, W, M, N, K, lda, ep, st);
+    case V_RING: return launch_ring<EPI>(A, W, M, N, K, lda, ep, st);
+    case V_IL: return launch_il<EPI>(A, W, M, N, K, lda, ep, st);
+    case 9: return launch_il<EPI, 1>(A, W, M, N, K, lda, ep, st);
+    case 10: return launch_il<EPI, 2>(A, W, M, N, K, lda, ep, st);
+    case 11: return launch_il<EPI, 3>(A, W, M, N, K, lda, ep, st);
+    default: break;
   }
+  const int nblocks = (N / BN) * ((M + BM - 1) / BM);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_reg2_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_reg2_kernel<EPI>, dim3(nblocks), dim3(256), 4 * TILE_BYTES, st, (const bf16*)A, (const bf16*)W, M, N,
+                     K, lda, ep);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -284,10 +574,10 @@ extern "C" int gram_gemm_bf16(const void* A, const void* W, void* C, int M, int 
   ep.ldc = ldc;
   switch (epilogue) {
     case GRAM_EPI_BF16:
-      if (!C || (ldc & 3)) return GRAM_E_ARG;
+      if (!C || (ldc & 7)) return GRAM_E_ARG;  // 16-byte row-aligned bf16 stores
       return launch<GRAM_EPI_BF16>(A, W, M, N, K, lda, ep, st);
     case GRAM_EPI_BF16_RELU:
-      if (!C || (ldc & 3)) return GRAM_E_ARG;
+      if (!C || (ldc & 7)) return GRAM_E_ARG;
       return launch<GRAM_EPI_BF16_RELU>(A, W, M, N, K, lda, ep, st);
     case GRAM_EPI_F32_ADD:
       if (!C || (ldc & 3)) return GRAM_E_ARG;
