@@ -106,7 +106,7 @@ __global__ void beam_init_kernel(gram_beam_state_t st, gram_trie_t tr, int start
 }
 
 __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gram_trie_t tr, const float* __restrict__ logits,
-                                                        const float* __restrict__ lse, int V, int cur_len, int nc_max) {
+                                                        const float* __restrict__ lse, int V, int cur_len, int nc_max, int rows_per_user) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [nc_max]
   __shared__ int s_pre[GRAM_MAX_BEAMS + 1];
@@ -150,7 +150,9 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
         const int r = row0 + k;
         const int e = tr.child_off[st.node[r]] + (ci - s_pre[k]);
         const int tok = tr.child_tok[e];
-        const float sc = (logits[(size_t)r * V + tok] - lse[r]) + st.beam_scores[r];
+        // rows_per_user == 1: the K beams of a user share one logits row (step 0: identical beams)
+        const int lr = rows_per_user == 1 ? b : r;
+        const float sc = (logits[(size_t)lr * V + tok] - lse[lr]) + st.beam_scores[r];
         key = ((unsigned long long)f2ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(k * V + tok));
       }
       keys[ci] = key;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
     const int p = idx / K, j = idx - p * K;
     int v;
     if (p < t) v = st.anc[(size_t)p * R + row0 + sel_par[j]];
-    else if (p == t) v = row0 + sel_par[j];
+    else if (p == t) v = rows_per_user == 1 ? b : row0 + sel_par[j];  // compact step: slot t holds one row per user
     else v = row0 + j;
     new_anc[idx] = v;
   }
@@ -319,9 +321,9 @@ extern "C" int gram_beam_init(const gram_beam_state_t* st, const gram_trie_t* tr
 }
 
 extern "C" int gram_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, const float* lse, int V,
-                              int cur_len, void* stream) {
+                              int cur_len, int rows_per_user, void* stream) {
   if (int e = check_state(st)) return e;
-  if (!tr || cur_len < 1 || cur_len >= st->Tmax || V < 2) return GRAM_E_ARG;
+  if (!tr || cur_len < 1 || cur_len >= st->Tmax || V < 2 || (rows_per_user != 1 && rows_per_user != st->K)) return GRAM_E_ARG;
   long long need = (long long)st->K * tr->max_fanout;
   int nc = 64;
   while (nc < need) nc <<= 1;
@@ -335,7 +337,7 @@ extern "C" int gram_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr
     attr_bytes = smem;
   }
   gram_prof::Scope prof(GRAM_K_BEAM, (hipStream_t)stream, 0.0);
-  hipLaunchKernelGGL(beam_step_kernel, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc, rows_per_user);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

@@ -146,13 +146,14 @@ int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const ui
   return 0;
 }
 
+// K = beams per user in THIS step's rows (1 for the compact step 0), R_cache = rows of the cache slots
 int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, const int32_t* anc, const uint8_t* mask, int B,
-                int N, int L, int K, int Tmax, int t, float* logits, void* st) {
+                int N, int L, int K, int R_cache, int Tmax, int t, float* logits, void* st) {
   const gram_model_desc_t& c = m->d;
   const int d = c.d_model, inner = c.n_heads * 64, F = c.d_ff, H = c.n_heads, V = c.vocab;
   const int R = B * K, S = N * L;
   const size_t bank_layer = (size_t)B * H * S * 64;
-  const size_t cache_layer = (size_t)Tmax * R * inner;
+  const size_t cache_layer = (size_t)Tmax * R_cache * inner;
   TRY(gram_embed_i32(c.embed_f32, tokens, w.xd, R, d, st));
   for (int i = 0; i < c.n_dec_layers; ++i) {
     TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln1[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
@@ -249,7 +250,7 @@ extern "C" int gram_decode_step(const gram_model_t* m, const int32_t* tokens, co
   if (t < 0 || t >= max_length - 1 || !logits) return GRAM_E_ARG;
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
-  return decode_step(m, w, tokens, anc, mask, B, N, L, K, max_length, t, logits, stream);
+  return decode_step(m, w, tokens, anc, mask, B, N, L, K, B * K, max_length, t, logits, stream);
 }
 
 extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K,
@@ -266,9 +267,13 @@ extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, co
   // fixed max_length-1 steps: finished users are padded exactly as BeamSearchScorer.process
   // pads them, so skipping HF's all-done early exit changes nothing and needs no host sync
   for (int t = 0; t + 1 < max_length; ++t) {
-    TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, K, max_length, t, w.logits, stream));
-    TRY(gram_row_lse(w.logits, w.lse, B * K, m->d.vocab, stream));
-    TRY(gram_beam_step(&w.beam, trie, w.logits, w.lse, m->d.vocab, t + 1, stream));
+    // step 0: every beam of a user holds the same start token and an empty cache, so the decoder,
+    // the cross-attention and the lm_head run on ONE row per user (HF runs K identical rows);
+    // gram_beam_step reads that shared row and points every beam's slot-0 ancestor at it
+    const int Kt = t == 0 ? 1 : K;
+    TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, Kt, B * K, max_length, t, w.logits, stream));
+    TRY(gram_row_lse(w.logits, w.lse, B * Kt, m->d.vocab, stream));
+    TRY(gram_beam_step(&w.beam, trie, w.logits, w.lse, m->d.vocab, t + 1, Kt, stream));
   }
   TRY(gram_beam_finalize(&w.beam, nret, max_length, sequences, scores, w.width, stream));
   if (width_host) {

@@ -138,9 +138,11 @@ int gram_beam_init(const gram_beam_state_t* st_host, const gram_trie_t* trie_hos
  *   -> + beam_scores -> top-2K over K*V (ties: lower flat index first) -> BeamSearchScorer.process
  *   -> next tokens / scores / parents, sequences and the ancestor table advanced in place.
  * Replaces HF 4.26 beam_search's per-step body and generation_trie.py:89-95's per-beam Python
- * callback (one D2H sync per beam per step in the reference). */
+ * callback (one D2H sync per beam per step in the reference).
+ * rows_per_user = K normally (logits/lse have one row per beam); 1 when the K beams of a user share
+ * one logits row and one self-attention cache row (step 0, where all beams are identical). */
 int gram_beam_step(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const float* logits,
-                   const float* lse, int V, int cur_len, void* stream);
+                   const float* lse, int V, int cur_len, int rows_per_user, void* stream);
 
 /* BeamSearchScorer.finalize: sequences int64 [B*nret][Tmax] (0-padded, EOS appended when it
  * fits), scores f32 [B*nret], out_width[0] = min(max hyp len + 1, max_length). */

@@ -61,7 +61,7 @@ def device_beam_search(logits_per_step, flat_trie, B, K, max_length, lp=1.0, nre
     for t in range(max_length - 1):
         lg = logits_per_step[t].contiguous()
         _lib.check(L.gram_row_lse(p(lg), p(lse), B * K, V, stream()), "row_lse")
-        _lib.check(L.gram_beam_step(C.byref(st), C.byref(ctrie), p(lg), p(lse), V, t + 1, stream()), "beam_step")
+        _lib.check(L.gram_beam_step(C.byref(st), C.byref(ctrie), p(lg), p(lse), V, t + 1, K, stream()), "beam_step")
         trace.append(dict(tokens=keep["tokens"].clone(), scores=keep["beam_scores"].clone(), seq=keep["seq"].clone(),
                           anc=keep["anc"].clone(), done=keep["done"].clone()))
     seqs = torch.empty(B * nret, max_length, dtype=torch.int64, device=DEV)
