@@ -24,6 +24,8 @@
 // Workgroup ids are remapped XCD-aware (ids i and i+8 share an XCD and its 4 MiB L2): every
 // XCD walks a contiguous range of tiles, n-tile fastest, so an A row-panel is fetched by one
 // XCD only and the (small) weight matrix stays L2-resident.
+#include <stdlib.h>
+
 #include "common.h"
 #include "prof.h"
 
@@ -34,6 +36,8 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
 enum { V_REG2 = 0, V_DMA = 1, V_DMA2 = 2, V_DMA_M256 = 3, V_DMA2_M256 = 4, V_DMA2_256SQ = 5, V_DMA_256SQ = 6, V_RING = 7, V_IL = 8 };
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
+int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain), see gemm_il_kernel
+
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -389,32 +393,113 @@ int launch_ring(const void* A, const void* W, int M, int N, int K, int lda, EpiA
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Row-contiguous epilogue for the 256x256 kernel (wave tile 64 rows x 128 columns).  The direct
+// epilogue touches 16 half-lines per store instruction (16 rows x 64 B) and is store-issue-bound
+// (ablation in tests/bench_gemm.py: ~60 % of the store cost remains even when the stores hit a
+// cache-resident region).  Here each wave transposes its accumulators through a PRIVATE 8-KiB LDS
+// patch (the second DMA stage is idle during the epilogue) and then issues stores/RMWs that cover
+// whole rows: 4 rows x 256 B (bf16) or 2 rows x 512 B (fp32) per instruction, full 128-B lines only.
+// 16-byte chunks are XOR-swizzled by row so both the transposing writes and the row reads are
+// conflict-free.  Wave-private: no workgroup barrier, only the wave's own LDS ordering.
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[8][4], char* patch /* this wave's 8 KiB */, int m0, int n0, int wm,
+                                              int wn, int lane, int M, const EpiArgs& ep) {
+  const int r16 = lane & 15, g = lane >> 4;
+  if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
+    // two passes of 32 rows x 128 cols bf16: patch[32][256 B], chunk c (16 B) stored at c ^ (row & 15)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = pass * 2 + jj;
+        const int row = jj * 16 + r16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          f32x4 v = acc[i][j];
+          if constexpr (EPI == GRAM_EPI_BF16_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          // 8-byte piece: columns i*16 + 4g .. +3  -> chunk (i*2 + g/2), half (g&1)
+          const int chunk = (i * 2 + (g >> 1)) ^ (row & 15);
+          *reinterpret_cast<uint2*>(patch + row * 256 + chunk * 16 + (g & 1) * 8) = pack_bf16x4(v);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4), c = lane & 15;
+        const uint4 val = *reinterpret_cast<const uint4*>(patch + row * 256 + ((c ^ (row & 15)) * 16));
+        const int m = m0 + wm * 64 + pass * 32 + row;
+        if (m < M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 8) = val;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    // fp32: four passes of 16 rows x 128 cols: patch[16][512 B], chunk c (16 B, 32 per row) at c ^ (row & 15)*2
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int chunk = (i * 4 + g) ^ ((r16 & 15) << 1);
+        *reinterpret_cast<f32x4*>(patch + r16 * 512 + chunk * 16) = acc[i][j];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 2 + (lane >> 5), c = lane & 31;
+        f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 512 + ((c ^ ((row & 15) << 1)) * 16));
+        const int m = m0 + wm * 64 + j * 16 + row;
+        if (m < M) {
+          f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4);
+          if constexpr (EPI == GRAM_EPI_F32_ADD) val += *pc;
+          *pc = val;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // V_IL: the 256x256 double-buffered DMA variant with the next k-tile's 8 DMA instructions
 // INTERLEAVED between MFMA groups (one DMA after every 8 MFMAs) instead of issued back-to-back
 // after the barrier: an LDS-DMA instruction costs ~100+ issue cycles inside a busy phase, and in the
 // plain variant all 8 waves pay 8 of them at the same moment while the MFMA pipe idles.
-template <int EPI, int ABL = 0>  // ABL (ablation, microbench only): 1 = DMA only, 2 = MFMA only
+template <int EPI, int ABL = 0>  // ABL (ablation, microbench only): 1 = DMA only, 2 = MFMA only, 3 = no stores
 __global__ __launch_bounds__(512, 2) void gemm_il_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                         int K, int lda, EpiArgs ep) {
+                                                         int K, int lda, EpiArgs ep, int ntiles, int stagger) {
+  // PERSISTENT: one workgroup per CU walks tiles t = round*G + slot.  With one 128-KiB workgroup per
+  // CU all CUs run in lockstep, so a per-tile launch leaves the output stream (up to 1.2 GB per GEMM)
+  // un-overlapped with MFMA work; here the stores of tile i drain while tile i+1 is fetched/computed,
+  // and the first DMA stage of tile i+1 is issued BEFORE the epilogue of tile i.
   constexpr int TB = 256, OPB = TB * BK * 2 /*32 KiB*/, STAGE = 2 * OPB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  int mt, nt;
-  tile_of_block(N / TB, mt, nt);
-  const int m0 = mt * TB, n0 = nt * TB;
   const int r16 = lane & 15, g = lane >> 4;
+  const int ntn = N / TB;
+  // XCD-aware slot: workgroups b, b+8, ... share an XCD; give each XCD a contiguous run of every round
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3, q = G >> 3, rr = G & 7;
+  const int slot = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
 
   const bf16* src[8];  // pieces 0-3: A groups 4w..4w+3, pieces 4-7: W groups 4w..4w+3
+  auto set_tile = [&](int tile, int& m0, int& n0) {
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    m0 = mt * TB;
+    n0 = nt * TB;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    src[i] = A + (size_t)min(m0 + row, M - 1) * lda + chunk * 8;
-    src[4 + i] = W + (size_t)(n0 + row) * K + chunk * 8;
-  }
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      src[i] = A + (size_t)min(m0 + row, M - 1) * lda + chunk * 8;
+      src[4 + i] = W + (size_t)(n0 + row) * K + chunk * 8;
+    }
+  };
   auto dma_piece = [&](int kt, int stage, int p) {
     char* dst = smem + stage * STAGE + (p >= 4 ? OPB : 0) + (wave * 4 + (p & 3)) * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[p] + kt * BK),
@@ -422,18 +507,7 @@ __global__ __launch_bounds__(512, 2) void gemm_il_kernel(const bf16* __restrict_
   };
 
   f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = K / BK;
-#pragma unroll
-  for (int p = 0; p < 8; ++p) dma_piece(0, 0, p);
-  __syncthreads();
-  // fragment registers are double-buffered: the ds_reads of k-step (ks+1) are issued before the
-  // MFMAs of k-step ks, so the LDS latency is exposed once per k-tile (after the barrier) only
-  bf16x8 fw0[8], fa0[4], fw1[8], fa1[4];
+  bf16x8 fw0[8], fa0[4];
   auto ldfrag = [&](bf16x8 (&fw)[8], bf16x8 (&fa)[4], const char* sa, const char* sw, int ks) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 128 + i * 16 + r16, ks * 4 + g));
@@ -453,26 +527,62 @@ __global__ __launch_bounds__(512, 2) void gemm_il_kernel(const bf16* __restrict_
       }
     }
   };
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int st = kt & 1;
-    const bool more = kt + 1 < nkt;
-    const char* sa = smem + st * STAGE;
-    const char* sw = sa + OPB;
-    ldfrag(fw0, fa0, sa, sw, 0);
-    ldfrag(fw1, fa1, sa, sw, 1);
-    mma(fw0, fa0, kt, st, 0, more);
-    mma(fw1, fa1, kt, st, 1, more);
-    __syncthreads();  // drains DMA(kt+1), fences the reads of stage st
+
+  const int nkt = K / BK;  // nkt is even or odd; the stage parity restarts at 0 for every tile
+  // De-synchronise the CUs: identical tiles keep all 256 workgroups in lockstep, so their epilogues
+  // would hit HBM as one 32-MB burst that every workgroup then waits out at its next barrier.  A start
+  // stagger of (slot % 8) * ~1/8 tile period spreads the store traffic over the whole period.
+  if (stagger > 0) {
+    const int units = ((slot & 7) * stagger * nkt) >> 3;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);  // 8 * 64 = 512 cycles
   }
-  if constexpr (ABL == 3) {  // ablation: no stores (keep acc live)
-    float keep = 0.f;
+  int tile = slot;
+  int m0 = 0, n0 = 0;
+  if (tile < ntiles) {
+    set_tile(tile, m0, n0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma_piece(0, 0, p);
+  }
+  while (tile < ntiles) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (keep == 123.456f) reinterpret_cast<float*>(ep.C)[0] = keep;
-  } else {
-    epilogue<EPI, 8>(acc, m0, n0, wm, wn, r16, g, M, ep);
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();  // stage 0 of this tile landed (and the previous tile's stores are issued/drained)
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int st = kt & 1;
+      const bool more = kt + 1 < nkt;
+      const char* sa = smem + st * STAGE;
+      const char* sw = sa + OPB;
+      ldfrag(fw0, fa0, sa, sw, 0);
+      mma(fw0, fa0, kt, st, 0, more);
+      ldfrag(fw0, fa0, sa, sw, 1);
+      mma(fw0, fa0, kt, st, 1, more);
+      __syncthreads();  // drains DMA(kt+1), fences the reads of stage st
+    }
+    // next tile: start its first stage now (both LDS stages are free), then store this tile
+    const int cur_m0 = m0, cur_n0 = n0;
+    tile += G;
+    if (tile < ntiles) {
+      set_tile(tile, m0, n0);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) dma_piece(0, 0, p);
+    }
+    if constexpr (ABL == 3) {  // ablation: no stores (keep acc live)
+      float keep = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (keep == 123.456f) reinterpret_cast<float*>(ep.C)[0] = keep;
+    } else if constexpr (ABL == 4) {  // ablation: same stores, but always into this workgroup's first tile (cache-resident)
+      epilogue<EPI, 8>(acc, (slot / ntn) * TB, (slot % ntn) * TB, wm, wn, r16, g, M, ep);
+    } else if constexpr (EPI == GRAM_EPI_KV_BANK) {
+      epilogue<EPI, 8>(acc, cur_m0, cur_n0, wm, wn, r16, g, M, ep);
+    } else {
+      // stage 1 is idle here (the next tile's first DMA went to stage 0): 8 waves x 8 KiB patches
+      epilogue_rows<EPI>(acc, smem + STAGE + wave * 8192, cur_m0, cur_n0, wm, wn, lane, M, ep);
+    }
   }
 }
 
@@ -480,7 +590,15 @@ template <int EPI, int ABL = 0>
 int launch_il(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
   constexpr int smem = 2 * 2 * 256 * 64 * 2;  // 128 KiB
   if (N % 256) return GRAM_E_ARG;
-  const int nblocks = (N / 256) * ((M + 255) / 256);
+  const int ntiles = (N / 256) * ((M + 255) / 256);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GRAM_E_ARG;
+    n_cu = prop.multiProcessorCount;
+  }
+  const int nblocks = ntiles < n_cu ? ntiles : n_cu;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_il_kernel<EPI, ABL>),
@@ -488,21 +606,24 @@ int launch_il(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_il_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
+  hipLaunchKernelGGL((gemm_il_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep,
+                     ntiles, g_stagger);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
 
 // Measured on MI355X (tests/bench_gemm.py, B = 512 shapes; TFLOP/s):
-//   M >= 32768 (encoder):  N=768,K=3072  V_IL 920 > V_DMA_M256 883 > V_DMA 829
-//                          other shapes  V_DMA_M256 871-883 >= V_IL 855-863 > V_DMA 806-823
-//   lm_head (N=32128):     V_DMA_M256 783 > V_DMA 614
-//   M ~ 10240 (decoder):   V_DMA 475-832 > V_DMA_M256 418-801 > V_IL 299-696
+//   M >= 32768 (encoder, bank):  V_IL (persistent 256x256, row-contiguous epilogue) 935-948 (521 for the
+//                                HBM-bound N=768,K=768 residual GEMM) > V_DMA_M256 780-815 > V_DMA
+//   lm_head (N = 32128, not a multiple of 256):  V_DMA_M256 783 > V_DMA 614
+//   M ~ 10240 (decoder):         V_DMA 475-832 > V_DMA_M256 418-801 > V_IL 299-696 (too few tiles per CU)
 int pick_variant(int M, int N, int K) {
+  (void)K;
   if (g_force_variant >= 0) return g_force_variant;
   const long tiles256 = (long)((M + 255) / 256) * (N / BN);
   if (tiles256 >= 2048) {  // >= 8 workgroups of 256x128 per CU: the big-tile variants pay off
-    if (N % 256 == 0 && K >= 2048 && M >= 32768) return V_IL;
+    static const int big = getenv("GRAM_GEMM_BIG") ? atoi(getenv("GRAM_GEMM_BIG")) : V_IL;  // A/B hook
+    if (N % 256 == 0 && M >= 32768) return big;
     return V_DMA_M256;
   }
   return V_DMA;
@@ -542,6 +663,7 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
     case 9: return launch_il<EPI, 1>(A, W, M, N, K, lda, ep, st);
     case 10: return launch_il<EPI, 2>(A, W, M, N, K, lda, ep, st);
     case 11: return launch_il<EPI, 3>(A, W, M, N, K, lda, ep, st);
+    case 12: return launch_il<EPI, 4>(A, W, M, N, K, lda, ep, st);
     default: break;
   }
   const int nblocks = (N / BN) * ((M + BM - 1) / BM);
@@ -561,6 +683,10 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
 }  // namespace
 
 extern "C" int gram_debug_set_gemm_variant(int v) {
+  if (v >= 1000) {  // 1000 + s: set the persistent kernel's start stagger instead
+    g_stagger = v - 1000;
+    return 0;
+  }
   g_force_variant = v;
   return 0;
 }

@@ -18,8 +18,11 @@ def main():
     ap.add_argument("--variants", default="0,1")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--stagger", type=int, default=-1)
     a = ap.parse_args()
     lib = _lib.load()
+    if a.stagger >= 0:
+        lib.gram_debug_set_gemm_variant(1000 + a.stagger)
     Me, Md = a.batch * 384, a.batch * 20
     shapes = [("enc qkv", Me, 2304, 768, _lib.EPI_BF16), ("enc o", Me, 768, 768, _lib.EPI_F32_ADD),
               ("enc wi", Me, 3072, 768, _lib.EPI_BF16_RELU), ("enc wo", Me, 768, 3072, _lib.EPI_F32_ADD),
