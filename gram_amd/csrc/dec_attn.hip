@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
   float* sm_m = reinterpret_cast<float*>(smem);             // [4][NB]
   float* sm_l = sm_m + 4 * NB;                              // [4][NB]
   float* sm_o = sm_l + 4 * NB;                              // [4][NB][64]
+  unsigned long long* sm_valid = reinterpret_cast<unsigned long long*>(sm_o + 4 * NB * 64);  // [2] valid-step bits
 
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,17 +123,52 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
       for (int nt = 0; nt < NT; ++nt) o[mt][nt] = mfma16(r.vf[mt], pf[nt], o[mt][nt]);
   };
 
+  // Fully masked 32-key steps (padded passages / padded tails) are never fetched: the algorithmic
+  // traffic is proportional to the VALID fused keys.  One bit per step (S <= 4096 -> <= 128 steps);
+  // the valid steps are dealt round-robin to the four waves.  A user with no valid key at all keeps
+  // every step: the reference's softmax over all-finfo.min scores is uniform over all S keys.
   const int nsteps = S >> 5;
+  {
+    bool flag = false;
+    if (tid < nsteps) {
+      const uint4* p = reinterpret_cast<const uint4*>(mk + 32 * tid);
+      const uint4 a = p[0], c2 = p[1];
+      flag = (a.x | a.y | a.z | a.w | c2.x | c2.y | c2.z | c2.w) != 0u;
+    }
+    const unsigned long long bal = __ballot(flag);
+    if (lane == 0 && wave < 2) sm_valid[wave] = bal;
+  }
+  __syncthreads();
+  unsigned long long v0 = sm_valid[0], v1 = sm_valid[1];
+  if ((v0 | v1) == 0ull) {
+    v0 = nsteps >= 64 ? ~0ull : ((1ull << nsteps) - 1ull);
+    v1 = nsteps > 64 ? ((nsteps >= 128 ? ~0ull : ((1ull << (nsteps - 64)) - 1ull))) : 0ull;
+  }
+  v0 = __builtin_amdgcn_readfirstlane((unsigned)v0) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v0 >> 32)) << 32);
+  v1 = __builtin_amdgcn_readfirstlane((unsigned)v1) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v1 >> 32)) << 32);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  int ord = 0;  // ordinal of the next valid step (wave-uniform scalar state)
+  auto next = [&](int s) -> int {
+    for (s = s + 1; s < nsteps; ++s) {
+      const unsigned long long bit = (s < 64 ? (v0 >> s) : (v1 >> (s - 64))) & 1ull;
+      if (bit) {
+        const bool mine = (ord & 3) == wv;
+        ++ord;
+        if (mine) return s;
+      }
+    }
+    return nsteps;
+  };
   StepRegs ra, rb;
-  int i = wave;
+  int i = next(-1);
   if (i < nsteps) load(ra, i);
   while (i < nsteps) {
-    int nx = i + 4;
+    int nx = next(i);
     if (nx < nsteps) load(rb, nx);
     compute(ra);
     i = nx;
     if (i >= nsteps) break;
-    nx = i + 4;
+    nx = next(i);
     if (nx < nsteps) load(ra, nx);
     compute(rb);
     i = nx;
@@ -178,7 +214,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
 template <int NT>
 int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int S,
                  hipStream_t st) {
-  const size_t smem = (size_t)(2 * 4 * NT * 16 + 4 * NT * 16 * 64) * sizeof(float);
+  const size_t smem = (size_t)(2 * 4 * NT * 16 + 4 * NT * 16 * 64) * sizeof(float) + 16;
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_kernel<NT>),
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restri
 
 extern "C" int gram_cross_attn_decode(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
                                       int B, int K, int H, int S, void* stream) {
-  if (B < 1 || K < 1 || K > GRAM_MAX_BEAMS || H < 1 || S < 32 || (S & 31)) return GRAM_E_ARG;
+  if (B < 1 || K < 1 || K > GRAM_MAX_BEAMS || H < 1 || S < 32 || (S & 31) || S > 4096) return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   gram_prof::Scope prof(GRAM_K_CROSS_ATTN, st, 4.0 * B * H * S * 64);  // K + V^T, bf16
   switch ((K + 15) / 16) {
