@@ -181,6 +181,18 @@ def main():
                    "avg_launch_us": 1e3 * xa["ms"] / max(xa["launches"], 1),
                    "algorithmic_bytes_per_launch": xa["work"] / max(xa["launches"], 1),
                    "share_of_kernel_time": xa["ms"] / max(sum(v["ms"] for v in kernel.values()), 1e-9)}
+        # HBM traffic per launch from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate rocprofv3 passes of this
+        # same command, gfx950 correction applied; profiles/*_pmc_traffic.json) -- only for the matching batch size
+        try:
+            pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1]))) if pmc_files else None
+            if pmc and pmc.get("batch") == B and args.backbone == "t5-base" and (N, L, K) == (3, 128, 20):
+                roof_xa["traffic"] = pmc["cross_attn_kernel"]["hbm_bytes_per_launch"]
+                roof_xa["traffic_source"] = "profiles/" + pmc_files[-1]
+                roof_gemm["traffic"] = pmc["gemm_all"]["hbm_bytes_per_launch_avg"]
+                roof_gemm["traffic_source"] = "profiles/" + pmc_files[-1]
+        except Exception:
+            pass
         dominant = max(kernel.items(), key=lambda kv: kv[1]["ms"])[0]
         result["roofline"] = roof_xa if dominant == "cross_attn" else roof_gemm
         result["roofline_cross_attn"] = roof_xa
