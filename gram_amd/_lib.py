@@ -60,6 +60,8 @@ class ModelDesc(C.Structure):
 SIGNATURES = {
     "gram_abi_version": (C.c_int, []),
     "gram_gemm_bf16": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KVBank), vp]),
+    "gram_gemm_bf16_lse": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "gram_lse_combine": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "gram_embed_i64": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "gram_embed_i32": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "gram_rmsnorm_bf16": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, f32, f32, vp, C.c_int, C.c_int, vp]),

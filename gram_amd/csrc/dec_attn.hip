@@ -24,6 +24,9 @@
 
 namespace {
 
+#ifndef STEP_SHIFT
+#define STEP_SHIFT 0  // measured: adjacent-step runs per wave (1, 2) are 5-7 % slower than interleaving
+#endif
 struct StepRegs {
   bf16x8 kf[2][2];
   bf16x8 vf[4];
@@ -116,6 +119,13 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
       l[nt] = l[nt] * alpha + ps;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) o[mt][nt] *= alpha;
+      // Keep alpha's register live past the scaling.  hipcc (ROCm 7.2) lowers the scaling to
+      // v_pk_mul_f32 with alpha broadcast from ONE register (op_sel_hi 0); when alpha dies here the
+      // allocator may reuse that register as the low half of a destination pair, and on gfx950 the
+      // instruction's high lane then multiplies by the freshly written low RESULT instead of alpha
+      // (observed: v_pk_mul_f32 v[138:139], v[46:47], v[138:139] op_sel_hi:[1,0] -> element 1 of one
+      // accumulator tile wrong whenever alpha != 1).  tools/check_isa_hazards.py scans every build.
+      asm volatile("" ::"v"(alpha));
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
     for (s = s + 1; s < nsteps; ++s) {
       const unsigned long long bit = (s < 64 ? (v0 >> s) : (v1 >> (s - 64))) & 1ull;
       if (bit) {
-        const bool mine = (ord & 3) == wv;
+        const bool mine = ((ord >> STEP_SHIFT) & 3) == wv;  // runs of 2^STEP_SHIFT adjacent valid steps per wave
         ++ord;
         if (mine) return s;
       }

@@ -44,6 +44,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 struct EpiArgs {
   void* C;
   int ldc;
+  float* lse_part;  // GRAM_EPI_F32_LSE: [M][N/64][2]
+  int lse_nblk;
   // KV bank
   bf16* bank_k;
   bf16* bank_vt;
@@ -118,6 +120,36 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
         const uint4 out = odd ? make_uint4(recv.x, recv.y, hi.x, hi.y) : make_uint4(lo.x, lo.y, recv.x, recv.y);
         const int n = n0 + wn * 16 * TNW + (i + (odd ? 1 : 0)) * 16 + 8 * (g >> 1);
         if (row_ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + n) = out;
+      }
+    } else if constexpr (EPI == GRAM_EPI_F32_LSE) {
+      // logits + softmax partials of this wave's 64-column block (TNW == 4): a lane holds 16 of the
+      // 64 values of row m (4 per n-tile), the other 48 sit in the lanes g^1, g^2, g^3 of the same r16
+      static_assert(TNW == 4, "F32_LSE epilogue is written for 64-column wave tiles");
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < TNW; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, acc[i][j][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < TNW; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm += __expf(acc[i][j][e] - mx);
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      if (row_ok) {
+#pragma unroll
+        for (int i = 0; i < TNW; ++i) {
+          const int n = n0 + wn * 16 * TNW + i * 16 + 4 * g;
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n) = acc[i][j];
+        }
+        if (g == 0) {
+          const int blk = (n0 >> 6) + wn;
+          float2 pr = make_float2(mx, sm);
+          *reinterpret_cast<float2*>(ep.lse_part + ((size_t)m * ep.lse_nblk + blk) * 2) = pr;
+        }
       }
     } else {
       if (!row_ok) continue;
@@ -651,6 +683,10 @@ int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiAr
 template <int EPI>
 int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
   gram_prof::Scope prof(GRAM_K_GEMM, st, 2.0 * M * N * K);
+  if constexpr (EPI == GRAM_EPI_F32_LSE) {  // written for the 64-column wave tiles only
+    return pick_variant(M, N, K) == V_DMA ? launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st)
+                                          : launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, st);
+  } else {
   switch (pick_variant(M, N, K)) {
     case V_DMA: return launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st);
     case V_DMA2: return launch_dma<EPI, 2, 2>(A, W, M, N, K, lda, ep, st);
@@ -678,6 +714,7 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
                      K, lda, ep);
   GRAM_CHECK_LAUNCH();
   return 0;
+  }
 }
 
 }  // namespace
@@ -689,6 +726,17 @@ extern "C" int gram_debug_set_gemm_variant(int v) {
   }
   g_force_variant = v;
   return 0;
+}
+
+extern "C" int gram_gemm_bf16_lse(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int K, int lda,
+                                  int ldc, void* stream) {
+  if (M < 1 || N % BN != 0 || K % BK != 0 || lda < K || (lda & 7) || !logits || !lse_part || (ldc & 3)) return GRAM_E_ARG;
+  EpiArgs ep{};
+  ep.C = logits;
+  ep.ldc = ldc;
+  ep.lse_part = lse_part;
+  ep.lse_nblk = N / 64;
+  return launch<GRAM_EPI_F32_LSE>(A, W, M, N, K, lda, ep, (hipStream_t)stream);
 }
 
 extern "C" int gram_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, int epilogue,

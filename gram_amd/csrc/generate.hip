@@ -56,6 +56,7 @@ struct Workspace {
   bf16* vcache;
   float* logits;    // [R][V]
   float* lse;       // [R]
+  float* lse_part;  // [R][V/64][2]
   // beam state
   gram_beam_state_t beam;
   int32_t* width;
@@ -85,6 +86,7 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   w.vcache = cv.take<bf16>(nl * Tmax * R * inner);
   w.logits = cv.take<float>(R * V);
   w.lse = cv.take<float>(R);
+  w.lse_part = cv.take<float>(R * (V / 64) * 2);
   gram_beam_state_t& s = w.beam;
   s.B = B;
   s.K = K;
@@ -148,7 +150,7 @@ int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const ui
 
 // K = beams per user in THIS step's rows (1 for the compact step 0), R_cache = rows of the cache slots
 int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, const int32_t* anc, const uint8_t* mask, int B,
-                int N, int L, int K, int R_cache, int Tmax, int t, float* logits, void* st) {
+                int N, int L, int K, int R_cache, int Tmax, int t, float* logits, float* lse_part, void* st) {
   const gram_model_desc_t& c = m->d;
   const int d = c.d_model, inner = c.n_heads * 64, F = c.d_ff, H = c.n_heads, V = c.vocab;
   const int R = B * K, S = N * L;
@@ -171,7 +173,10 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   }
   const float scale = c.tie_word_embeddings ? 1.0f / sqrtf((float)d) : 1.f;  // gram_t5.py:249-252
   TRY(gram_rmsnorm_bf16(w.xd, c.dec_final_ln, w.hd, R, d, c.eps, scale, nullptr, 1, 1, st));
-  TRY(gram_gemm_bf16(w.hd, c.lm_head_bf16, logits, R, V, d, d, V, GRAM_EPI_F32, nullptr, st));
+  if (lse_part)  // log-softmax normaliser partials straight from the accumulators (no re-read of the logits)
+    TRY(gram_gemm_bf16_lse(w.hd, c.lm_head_bf16, logits, lse_part, R, V, d, d, V, st));
+  else
+    TRY(gram_gemm_bf16(w.hd, c.lm_head_bf16, logits, R, V, d, d, V, GRAM_EPI_F32, nullptr, st));
   return 0;
 }
 
@@ -250,7 +255,7 @@ extern "C" int gram_decode_step(const gram_model_t* m, const int32_t* tokens, co
   if (t < 0 || t >= max_length - 1 || !logits) return GRAM_E_ARG;
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
-  return decode_step(m, w, tokens, anc, mask, B, N, L, K, B * K, max_length, t, logits, stream);
+  return decode_step(m, w, tokens, anc, mask, B, N, L, K, B * K, max_length, t, logits, nullptr, stream);
 }
 
 extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K,
@@ -271,8 +276,8 @@ extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, co
     // the cross-attention and the lm_head run on ONE row per user (HF runs K identical rows);
     // gram_beam_step reads that shared row and points every beam's slot-0 ancestor at it
     const int Kt = t == 0 ? 1 : K;
-    TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, Kt, B * K, max_length, t, w.logits, stream));
-    TRY(gram_row_lse(w.logits, w.lse, B * Kt, m->d.vocab, stream));
+    TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, Kt, B * K, max_length, t, w.logits, w.lse_part, stream));
+    TRY(gram_lse_combine(w.lse_part, w.lse, B * Kt, m->d.vocab / 64, stream));
     TRY(gram_beam_step(&w.beam, trie, w.logits, w.lse, m->d.vocab, t + 1, Kt, stream));
   }
   TRY(gram_beam_finalize(&w.beam, nret, max_length, sequences, scores, w.width, stream));

@@ -85,7 +85,36 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
   }
 }
 
+// lse[row] from the lm_head epilogue's per-64-column partials (max, sum exp(x - max)): one wave per row
+__global__ __launch_bounds__(256) void lse_combine_kernel(const float* __restrict__ part, float* __restrict__ lse, int M, int nblk) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float2* p = reinterpret_cast<const float2*>(part + (size_t)row * nblk * 2);
+  float m = -INFINITY, s = 0.f;
+  for (int i = lane; i < nblk; i += 64) {
+    const float2 v = p[i];
+    if (v.x > m) {
+      s *= __expf(m - v.x);
+      m = v.x;
+    }
+    s += v.y * __expf(v.x - m);
+  }
+  const float wm = wave_max(m);
+  s *= (m == -INFINITY) ? 0.f : __expf(m - wm);
+  s = wave_sum(s);
+  if (lane == 0) lse[row] = wm + logf(s);
+}
+
 }  // namespace
+
+extern "C" int gram_lse_combine(const float* lse_part, float* lse, int M, int nblk, void* stream) {
+  if (M < 1 || nblk < 1) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_LSE, (hipStream_t)stream, 8.0 * M * nblk);
+  hipLaunchKernelGGL(lse_combine_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, lse_part, lse, M, nblk);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int gram_embed_i64(const float* table, const int64_t* ids, float* x, int rows, int d, void* stream) {
   if (rows < 1 || (d & 3)) return GRAM_E_ARG;

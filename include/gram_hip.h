@@ -40,7 +40,8 @@ enum gram_epilogue {
   GRAM_EPI_BF16_RELU = 1, /* C_bf16[m][n]  = max(acc, 0)        (T5DenseActDense wi+ReLU) */
   GRAM_EPI_F32_ADD = 2,   /* C_f32[m][n]  += acc                (residual add)            */
   GRAM_EPI_F32 = 3,       /* C_f32[m][n]   = acc                (lm_head logits)          */
-  GRAM_EPI_KV_BANK = 4    /* scatter into the fused K bank / V^T bank (see below)         */
+  GRAM_EPI_KV_BANK = 4,   /* scatter into the fused K bank / V^T bank (see below)         */
+  GRAM_EPI_F32_LSE = 5    /* GRAM_EPI_F32 + per-(row, 64-column block) softmax partials       */
 };
 
 /* Fused cross-attention KV bank for B users, S = N*L fused tokens, n_layers decoder layers:
@@ -60,6 +61,13 @@ typedef struct {
  * rows m = b*S + s and columns n = (layer*2 + which)*inner + h*64 + d. */
 int gram_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc,
                    int epilogue, const gram_kv_bank_t* bank_host, void* stream);
+
+/* lm_head with the log-softmax normaliser fused: logits as GRAM_EPI_F32, plus for every row and every
+ * 64-column block the pair (max, sum exp(x - max)) in lse_part f32 [M][N/64][2]; gram_lse_combine folds
+ * them into lse[M] = log sum_v exp(logits[m][v]) without re-reading the logits (gram_row_lse does). */
+int gram_gemm_bf16_lse(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int K, int lda,
+                       int ldc, void* stream);
+int gram_lse_combine(const float* lse_part, float* lse, int M, int nblk, void* stream);
 
 /* x[row][:] = table[ids[row]][:]   (embed_tokens, gram_t5_modeling.py:1091). */
 int gram_embed_i64(const float* table, const int64_t* ids, float* x, int rows, int d, void* stream);

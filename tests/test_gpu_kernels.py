@@ -137,7 +137,10 @@ def test_enc_self_attn(G, L):
 
 
 # ------------------------------------------------------------------------------------ cross attention
-@pytest.mark.parametrize("K,S", [(20, 384), (1, 32), (16, 96), (50, 2688), (33, 160)])
+# K <= 16 with several 32-key steps per wave once hid a mis-scheduled packed multiply (dims 48-63 wrong,
+# tools/check_isa_hazards.py): every beam-tile count (1..4) is covered with short and long banks.
+@pytest.mark.parametrize("K,S", [(20, 384), (1, 32), (16, 96), (50, 2688), (33, 160), (1, 384), (8, 384), (16, 2688), (8, 160),
+                                 (17, 1024), (48, 640), (64, 384)])
 def test_cross_attn_decode(G, K, S):
     from gram_amd import _lib
     B, H = 3, 2
@@ -157,7 +160,8 @@ def test_cross_attn_decode(G, K, S):
     qh = q.float().cpu().view(B, K, H, 64).permute(0, 2, 1, 3)  # (B,H,K,64)
     ext = ((1.0 - mask.float()) * O.FMIN)[:, None, None, :]
     ref = O._attend(qh, kb.float().cpu(), vt.float().cpu().transpose(2, 3), ext).reshape(B * K, inner)
-    assert torch.allclose(out.float().cpu(), ref, atol=2.5e-2, rtol=2e-2)
+    # bf16 P and bf16 output on O(1) values: 1e-2 abs (observed max ~6e-3)
+    assert torch.allclose(out.float().cpu(), ref, atol=1e-2, rtol=1e-2)
 
 
 def test_cross_attn_all_masked_user(G):
@@ -275,3 +279,21 @@ def test_beam_search_real_trie_shapes(G):
     assert err == 0
     assert dseq.tolist() == seqs.tolist()
     assert torch.allclose(dscore, scores, atol=2e-5, rtol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 256, 128), (2560, 32128, 768), (9000, 32128, 768)])
+def test_lm_head_fused_lse(G, M, N, K):
+    """gram_gemm_bf16_lse + gram_lse_combine == logits (fp32) and logsumexp over the vocabulary, for both
+    the 128x128 (small M) and the 256x128 (large M) tile variants."""
+    from gram_amd import _lib
+    A, W = G.bf(_r(M, K, seed=31, scale=2.0)), G.bf(_r(N, K, seed=32, scale=K ** -0.5))
+    logits = torch.empty(M, N, dtype=torch.float32, device=G.DEV)
+    part = torch.full((M, N // 64, 2), float("nan"), dtype=torch.float32, device=G.DEV)
+    lse = torch.empty(M, dtype=torch.float32, device=G.DEV)
+    L_ = G.lib()
+    _lib.check(L_.gram_gemm_bf16_lse(G.p(A), G.p(W), G.p(logits), G.p(part), M, N, K, K, N, G.stream()), "gemm_lse")
+    _lib.check(L_.gram_lse_combine(G.p(part), G.p(lse), M, N // 64, G.stream()), "lse_combine")
+    ref = A.float() @ W.float().T
+    assert torch.allclose(logits, ref, atol=2e-3, rtol=1e-4)
+    assert torch.allclose(lse, torch.logsumexp(logits, -1), atol=2e-5, rtol=1e-6)
+    assert not torch.isnan(part).any()
