@@ -17,6 +17,7 @@ from oracle import gram_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+LOGIT_TOL = 0.06  # observed 0.015-0.03 (bf16 operands through all decoder layers, logits O(1))
 
 
 @pytest.fixture(scope="module")
@@ -136,9 +137,10 @@ def test_decode_steps_vs_oracle(gpu, name):
         _lib.check(rc, "gram_decode_step")
         got = logits.cpu()
         # logits are O(1) (tied head, d^-0.5 rescale); bf16 operand error accumulates over the decoder layers
-        assert (got - ref).abs().max() < 0.12, (t, float((got - ref).abs().max()))
         lp_err = (torch.log_softmax(got, -1) - torch.log_softmax(ref, -1)).abs().max()
-        assert lp_err < 0.12, (t, float(lp_err))
+        print(f"[decode step {t}] max |logit err| {float((got - ref).abs().max()):.4f}  max |log-prob err| {float(lp_err):.4f}")
+        assert (got - ref).abs().max() < LOGIT_TOL, (t, float((got - ref).abs().max()))
+        assert lp_err < LOGIT_TOL, (t, float(lp_err))
         parent = torch.cat([torch.randperm(K, generator=g) + b * K for b in range(B)])
         st.reorder(parent)
         a = anc.cpu()
@@ -170,6 +172,7 @@ def _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol, lp=1.0):
         return tuple(row)
 
     n_order_diff = 0
+    max_dev = 0.0
     for b in range(B):
         dev = [strip(r) for r in seqs[b * K:(b + 1) * K]]
         orc = [strip(r) for r in rseqs[b * K:(b + 1) * K]]
@@ -186,12 +189,14 @@ def _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol, lp=1.0):
                 exact = O.sequence_logprob(sd, oc, ids[b:b + 1], mask[b:b + 1], list(s)) / (len(s) - 1) ** lp
                 assert exact > kth - 2 * tol, (b, s, exact, kth)
             assert abs(float(dsc[i]) - exact) < tol, (b, s, float(dsc[i]), exact)
+            max_dev = max(max_dev, abs(float(dsc[i]) - exact))
         # order: any inversion w.r.t. oracle scores must be within tolerance
         ex = [osc.get(s) for s in dev]
         for i in range(K - 1):
             if ex[i] is not None and ex[i + 1] is not None and ex[i] < ex[i + 1]:
                 assert ex[i + 1] - ex[i] < 2 * tol
                 n_order_diff += 1
+    print(f"[generate parity] max |score - oracle score of the same sequence| = {max_dev:.4f} (tol {tol}); tolerated order inversions {n_order_diff}")
     return n_order_diff
 
 
@@ -213,7 +218,7 @@ def test_generate_vs_oracle(gpu, name, B, N, L, K, n_items, depth):
     assert out["sequences"].shape[0] == B * K and out["sequences"].dtype == torch.int64
     assert out["sequences"].shape[1] == ref["sequences"].shape[1]
     assert bool((out["sequences"][:, 0] == 0).all())
-    _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=0.06)
+    _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=0.02)
 
 
 def test_generate_matches_reference_golden(gpu, golden_dir):
@@ -229,7 +234,7 @@ def test_generate_matches_reference_golden(gpu, golden_dir):
         out = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=len(cands[0]), prefix_allowed_tokens_fn=fn,
                          num_beams=K, num_return_sequences=K, length_penalty=1.0)
         ref = {"sequences": torch.from_numpy(z[f"c{ci}_sequences"]), "sequences_scores": torch.from_numpy(z[f"c{ci}_scores"])}
-        _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=0.06)
+        _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=0.02)
 
 
 def test_metric_parity_population(gpu):
