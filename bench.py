@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--beams", type=int, default=20)
     ap.add_argument("--cpu-users", type=int, default=2, help="users in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL on ROCm)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: all ranks use cuda:0 (with --backend gloo; RCCL needs one GPU per rank)")
     return ap.parse_args()
 
 
@@ -67,11 +70,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if args.share_device:
+        local_rank = 0
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
@@ -124,7 +132,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
