@@ -304,6 +304,56 @@ __global__ void beam_finalize_kernel(gram_beam_state_t st, int nret, int max_len
   atomicMax(out_width, w);
 }
 
+// HF 4.26 greedy_search step (num_beams == 1): one thread per user.  argmax of the raw logits over the
+// Trie children (first maximum wins, like torch.argmax on the -inf-masked row; no children -> index 0),
+// finished users emit pad.  done[b] doubles as HF's (1 - unfinished_sequences); n_hyps[b] records the
+// sequence length at which the user finished (0 = still running) for the final width.
+__global__ void greedy_step_kernel(gram_beam_state_t st, gram_trie_t tr, const float* __restrict__ logits, int V, int cur_len) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= st.B) return;
+  const int T = st.Tmax;
+  int tok = st.pad, next_node = -1;
+  if (!st.done[b]) {
+    const int nd = st.node[b];
+    tok = 0;  // argmax of an all -inf row
+    if (nd >= 0) {
+      const int lo = tr.child_off[nd], hi = tr.child_off[nd + 1];
+      float best = -INFINITY;
+      bool any = false;
+      for (int e = lo; e < hi; ++e) {
+        const int c = tr.child_tok[e];
+        const float v = logits[(size_t)b * V + c];
+        // children are sorted by token: strict > keeps the first maximum; a -inf logit at a lower index than
+        // an allowed -inf one cannot happen for finite model outputs, NaN is never selected over a number
+        if (!any || v > best) {
+          best = v;
+          tok = c;
+          next_node = tr.child_node[e];
+          any = true;
+        }
+      }
+    }
+    if (tok == st.eos) {
+      st.done[b] = 1;
+      st.n_hyps[b] = cur_len + 1;
+    }
+  }
+  st.seq[(size_t)b * T + cur_len] = tok;
+  st.tokens[b] = tok;
+  st.node[b] = next_node;
+}
+
+__global__ void greedy_finalize_kernel(gram_beam_state_t st, int max_length, int64_t* __restrict__ sequences,
+                                       int32_t* __restrict__ out_width) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= st.B) return;
+  const int T = st.Tmax;
+  for (int p = 0; p < max_length; ++p) sequences[(size_t)b * max_length + p] = st.seq[(size_t)b * T + p];
+  // HF stops as soon as every row is finished: width = the longest finished length (max_length if any row never finished)
+  const int len = st.n_hyps[b] > 0 ? st.n_hyps[b] : max_length;
+  atomicMax(out_width, len);
+}
+
 }  // namespace
 
 static int check_state(const gram_beam_state_t* st) {
@@ -338,6 +388,28 @@ extern "C" int gram_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr
   }
   gram_prof::Scope prof(GRAM_K_BEAM, (hipStream_t)stream, 0.0);
   hipLaunchKernelGGL(beam_step_kernel, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc, rows_per_user);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gram_greedy_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, int V, int cur_len,
+                               void* stream) {
+  if (int e = check_state(st)) return e;
+  if (!tr || st->K != 1 || cur_len < 1 || cur_len >= st->Tmax || V < 2) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_BEAM, (hipStream_t)stream, 0.0);
+  hipLaunchKernelGGL(greedy_step_kernel, dim3((st->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, *st, *tr, logits, V, cur_len);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gram_greedy_finalize(const gram_beam_state_t* st, int max_length, int64_t* sequences, int32_t* out_width,
+                                    void* stream) {
+  if (int e = check_state(st)) return e;
+  if (st->K != 1 || max_length != st->Tmax) return GRAM_E_ARG;
+  hipError_t e = hipMemsetAsync(out_width, 0, sizeof(int32_t), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(greedy_finalize_kernel, dim3((st->B + 127) / 128), dim3(128), 0, (hipStream_t)stream, *st, max_length, sequences,
+                     out_width);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

@@ -262,13 +262,20 @@ extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, co
                              int nret, int max_length, float length_penalty, const gram_trie_t* trie, void* workspace,
                              int64_t workspace_bytes, int64_t* sequences, float* scores, int32_t* width_host, void* stream) {
   TRY(check_shapes(m, B, N, L, K, max_length));
-  if (!trie || nret < 1 || nret > K || !sequences || !scores) return GRAM_E_ARG;
+  if (!trie || nret < 1 || nret > K || !sequences || (!scores && K != 1)) return GRAM_E_ARG;
   if ((long long)K * trie->max_fanout > 16384) return GRAM_E_ARG;
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
   w.beam.length_penalty = length_penalty;
   TRY(encode(m, w, input_ids, mask, B, N, L, stream));
   TRY(gram_beam_init(&w.beam, trie, /*decoder_start_token_id=*/0, stream));
+  if (K == 1) {  // HF: num_beams == 1 -> greedy_search (raw logits, no hypotheses, no scores)
+    for (int t = 0; t + 1 < max_length; ++t) {
+      TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, 1, B, max_length, t, w.logits, nullptr, stream));
+      TRY(gram_greedy_step(&w.beam, trie, w.logits, m->d.vocab, t + 1, stream));
+    }
+    TRY(gram_greedy_finalize(&w.beam, max_length, sequences, w.width, stream));
+  } else {
   // fixed max_length-1 steps: finished users are padded exactly as BeamSearchScorer.process
   // pads them, so skipping HF's all-done early exit changes nothing and needs no host sync
   for (int t = 0; t + 1 < max_length; ++t) {
@@ -281,6 +288,7 @@ extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, co
     TRY(gram_beam_step(&w.beam, trie, w.logits, w.lse, m->d.vocab, t + 1, Kt, stream));
   }
   TRY(gram_beam_finalize(&w.beam, nret, max_length, sequences, scores, w.width, stream));
+  }
   if (width_host) {
     int32_t host[2] = {0, 0};
     hipError_t e = hipMemcpyAsync(&host[0], w.width, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);

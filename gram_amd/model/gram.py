@@ -350,14 +350,17 @@ class GRAM(nn.Module):
         flat = self._flat_trie(prefix_allowed_tokens_fn)
         ctrie, _keep = flat.to_device(dev)
         ws = self._get_workspace(handle, B, N, Lp, K, int(max_length))
+        if K == 1 and nret != 1:
+            raise ValueError("num_return_sequences must be 1 for greedy search (num_beams == 1), as in HF generate")
         seqs = torch.empty(B * nret, int(max_length), dtype=torch.int64, device=dev)
-        scores = torch.empty(B * nret, dtype=torch.float32, device=dev)
+        # num_beams == 1 is HF's greedy_search: it has no sequences_scores
+        scores = torch.empty(B * nret, dtype=torch.float32, device=dev) if K > 1 else None
         width = C.c_int32(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             rc = lib.gram_generate(handle, ids.data_ptr(), mask.data_ptr(), B, N, Lp, K, nret, int(max_length),
                                    float(length_penalty), C.byref(ctrie), ws.data_ptr(), ws.numel(), seqs.data_ptr(),
-                                   scores.data_ptr(), C.byref(width), stream)
+                                   scores.data_ptr() if scores is not None else None, C.byref(width), stream)
         _lib.check(rc, "gram_generate")
         seqs = seqs[:, : width.value]
         if not return_dict_in_generate:

@@ -152,6 +152,14 @@ int gram_beam_init(const gram_beam_state_t* st_host, const gram_trie_t* trie_hos
 int gram_beam_step(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const float* logits,
                    const float* lse, int V, int cur_len, int rows_per_user, void* stream);
 
+/* HF 4.26 greedy_search (generate with num_beams == 1; BASELINE configs[0]) on the same state with K = 1:
+ * argmax of the RAW logits over the Trie children (first maximum), finished users emit pad; finalize copies
+ * the sequences (i64 [B][max_length]) and reports the width HF would return (it stops once all rows hit EOS). */
+int gram_greedy_step(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const float* logits, int V,
+                     int cur_len, void* stream);
+int gram_greedy_finalize(const gram_beam_state_t* st_host, int max_length, int64_t* sequences, int32_t* out_width,
+                         void* stream);
+
 /* BeamSearchScorer.finalize: sequences int64 [B*nret][Tmax] (0-padded, EOS appended when it
  * fits), scores f32 [B*nret], out_width[0] = min(max hyp len + 1, max_length). */
 int gram_beam_finalize(const gram_beam_state_t* st_host, int nret, int max_length, int64_t* sequences,
@@ -218,7 +226,8 @@ int gram_decode_step(const gram_model_t* m, const int32_t* tokens, const int32_t
  * encoder -> late fusion -> bank -> max_length-1 constrained beam-search steps -> finalize.
  * sequences i64 [B*nret][max_length], scores f32 [B*nret]; *width_host receives
  * min(max hyp len + 1, max_length) (the column count HF returns) if non-NULL, which costs one
- * stream synchronise.  Returns GRAM_E_BEAM if the device flagged an impossible beam state. */
+ * stream synchronise.  Returns GRAM_E_BEAM if the device flagged an impossible beam state.
+ * K == 1 follows HF's dispatch to greedy_search: `scores` may be NULL and is not written. */
 int gram_generate(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L,
                   int K, int nret, int max_length, float length_penalty, const gram_trie_t* trie_host,
                   void* workspace, int64_t workspace_bytes, int64_t* sequences, float* scores,

@@ -510,6 +510,38 @@ def beam_search(
     return decoded, best_scores
 
 
+def greedy_search(
+    step_fn: Callable[[Tensor], Tensor],
+    batch_size: int,
+    max_length: int,
+    prefix_fn: Optional[Callable[[int, Tensor], List[int]]],
+    pad_token_id: int = 0,
+    eos_token_id: int = 1,
+    decoder_start_token_id: int = 0,
+) -> Tensor:
+    """HF 4.26 ``greedy_search`` (what ``generate`` runs for num_beams=1, do_sample=False; BASELINE
+    configs[0]).  The prefix constraint is applied to the raw logits (-inf outside the allowed list; an empty
+    list leaves the whole row -inf and argmax returns index 0), finished rows emit pad, the loop ends when every
+    row has produced EOS or at max_length.  Returns sequences (B, T) int64; there are no sequences_scores."""
+    B = batch_size
+    input_ids = torch.full((B, 1), decoder_start_token_id, dtype=torch.long)
+    unfinished = torch.ones(B, dtype=torch.long)
+    while True:
+        logits = step_fn(input_ids[:, -1]).float()
+        if prefix_fn is not None:
+            mask = torch.full_like(logits, -math.inf)
+            for b in range(B):
+                mask[b, prefix_fn(b, input_ids[b])] = 0
+            logits = logits + mask
+        nxt = torch.argmax(logits, dim=-1)
+        nxt = nxt * unfinished + pad_token_id * (1 - unfinished)
+        input_ids = torch.cat([input_ids, nxt[:, None]], dim=-1)
+        unfinished = unfinished * (nxt != eos_token_id).long()
+        if int(unfinished.max()) == 0 or input_ids.shape[1] >= max_length:
+            break
+    return input_ids
+
+
 def generate(
     sd: Dict[str, Tensor],
     cfg: OracleConfig,
@@ -540,6 +572,10 @@ def generate(
             st = DecodeState(cross=cross_kv(sd, cfg, enc.repeat_interleave(K, dim=0)), enc_mask_ext=ext, rows_per_bank=1)
         else:
             st = DecodeState(cross=cross_kv(sd, cfg, enc), enc_mask_ext=ext, rows_per_bank=K)
+        if K == 1:  # HF dispatches num_beams == 1 to greedy_search
+            seqs = greedy_search(lambda tok: decoder_step(sd, cfg, tok, st), B, max_length, prefix_allowed_tokens_fn,
+                                 cfg.pad_token_id, cfg.eos_token_id, cfg.decoder_start_token_id)
+            return {"sequences": seqs, "sequences_scores": None, "encoder_last_hidden_state": enc}
         seqs, scores = beam_search(
             lambda tok: decoder_step(sd, cfg, tok, st),
             st.reorder,

@@ -92,3 +92,28 @@ def test_early_exit_is_result_neutral(seed):
                                   1.0, early_exit=early))
     assert outs[0][0].tolist() == outs[1][0].tolist()
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_greedy_search_hand_worked():
+    """HF greedy_search (num_beams = 1): argmax over the allowed tokens of the RAW logits, finished rows
+    emit pad, the loop stops when every row has produced EOS; tokens outside the Trie never win."""
+    cands = [[0, 2, 1], [0, 3, 4, 1]]
+
+    def rows(*dists, V=8):
+        out = []
+        for d in dists:
+            r = torch.full((V,), -5.0)
+            for k, v in d.items():
+                r[k] = v
+            out.append(r)
+        return torch.stack(out)
+
+    steps = iter([rows({2: 1.0, 3: 2.0, 5: 9.0}, {2: 3.0, 3: 2.0}),   # token 5 has the largest logit but is not allowed
+                  rows({4: 0.5, 1: 0.1}, {1: 0.3}),                  # row 0: only 4 is allowed after [0,3]; row 1: EOS
+                  rows({1: 1.0}, {6: 5.0})])                         # row 1 is finished: emits pad whatever its logits
+    seq = O.greedy_search(lambda tok: next(steps), 2, 4, O.prefix_allowed_tokens_fn(O.Trie(cands)))
+    assert seq.tolist() == [[0, 3, 4, 1], [0, 2, 1, 0]]
+    # early stop: both rows finish at length 3 although max_length is 4
+    steps = iter([rows({2: 1.0}, {2: 1.0}), rows({1: 0.0}, {1: 0.0}), rows({1: 0.0}, {1: 0.0})])
+    seq = O.greedy_search(lambda tok: next(steps), 2, 4, O.prefix_allowed_tokens_fn(O.Trie([[0, 2, 1], [0, 3, 4, 1]])))
+    assert seq.tolist() == [[0, 2, 1], [0, 2, 1]]

@@ -297,3 +297,29 @@ def test_lm_head_fused_lse(G, M, N, K):
     assert torch.allclose(logits, ref, atol=2e-3, rtol=1e-4)
     assert torch.allclose(lse, torch.logsumexp(logits, -1), atol=2e-5, rtol=1e-6)
     assert not torch.isnan(part).any()
+
+
+def test_greedy_step_bit_exact_vs_oracle(G):
+    """gram_greedy_step / gram_greedy_finalize on given logits == the oracle's restated HF greedy_search."""
+    from gram_amd import _lib
+    from gram_amd.utils import generation_trie as gt
+    cands = _tries()["ragged"]
+    B, V = 37, 64
+    max_length = max(len(c) for c in cands)
+    g = torch.Generator().manual_seed(5)
+    logits = [torch.randn(B, V, generator=g) * 3 for _ in range(max_length - 1)]
+    it = iter(logits)
+    ref = O.greedy_search(lambda tok: next(it), B, max_length, O.prefix_allowed_tokens_fn(O.Trie(cands)))
+    st, keep = G.make_beam_state(B, 1, max_length)
+    ctrie, keep2 = gt.FlatTrie(gt.Trie(cands)).to_device(torch.device(G.DEV))
+    L_ = G.lib()
+    _lib.check(L_.gram_beam_init(C.byref(st), C.byref(ctrie), 0, G.stream()), "init")
+    for t in range(max_length - 1):
+        lg = logits[t].to(G.DEV).contiguous()
+        _lib.check(L_.gram_greedy_step(C.byref(st), C.byref(ctrie), G.p(lg), V, t + 1, G.stream()), "greedy_step")
+    seqs = torch.empty(B, max_length, dtype=torch.int64, device=G.DEV)
+    width = torch.zeros(4, dtype=torch.int32, device=G.DEV)
+    _lib.check(L_.gram_greedy_finalize(C.byref(st), max_length, G.p(seqs), G.p(width), G.stream()), "greedy_finalize")
+    torch.cuda.synchronize()
+    assert int(width[0]) == ref.shape[1]
+    assert seqs[:, : ref.shape[1]].cpu().tolist() == ref.tolist()
