@@ -71,6 +71,7 @@ SIGNATURES = {
     "gram_row_lse": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "gram_beam_init": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), C.c_int, vp]),
     "gram_beam_step": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "gram_beam_step_sparse": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "gram_greedy_step": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), vp, C.c_int, C.c_int, vp]),
     "gram_greedy_finalize": (C.c_int, [C.POINTER(BeamState), C.c_int, vp, vp, vp]),
     "gram_beam_finalize": (C.c_int, [C.POINTER(BeamState), C.c_int, C.c_int, vp, vp, vp, vp]),

@@ -106,9 +106,11 @@ __global__ void beam_init_kernel(gram_beam_state_t st, gram_trie_t tr, int start
 }
 
 __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gram_trie_t tr, const float* __restrict__ logits,
-                                                        const float* __restrict__ lse, int V, int cur_len, int nc_max, int rows_per_user) {
+                                                        const float* __restrict__ lse, int V, int cur_len, int nc_max, int rows_per_user,
+                                                        const bf16* __restrict__ hd, const bf16* __restrict__ emb, int d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [nc_max]
+  float* s_log = reinterpret_cast<float*>(keys + nc_max);                   // [nc_max / K] shared step-0 logits
   __shared__ int s_pre[GRAM_MAX_BEAMS + 1];
   __shared__ int s_C, s_NC, s_isdone;
   __shared__ float sel_score[GRAM_MAX_BEAMS];
@@ -140,7 +142,62 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
   const int C = s_C, NC = s_NC;
   const bool isdone = s_isdone != 0;
 
-  if (!isdone) {
+  if (!isdone && logits == nullptr) {
+    // SPARSE mode: the lm_head GEMM stored only the softmax partials (lse); the logits of the <= K*fan-out
+    // allowed tokens are recomputed here as h[row] . E[tok] (bf16 operands, fp32 accumulate; 8 lanes per
+    // candidate, 16-byte loads).  The [rows][V] logits tensor (5 GB per step at B = 2048) is never written.
+    for (int ci = C + tid; ci < NC; ci += 256) keys[ci] = 0ull;
+    const int sub = tid & 7, grp = tid >> 3;
+    const bool shared0 = rows_per_user == 1;  // step 0: all K beams sit on the same node and the same row
+    const int nuniq = shared0 ? s_pre[1] : C;
+    const int per = d >> 3;                   // elements per lane
+    for (int base = 0; base < nuniq; base += 32) {
+      const int ci = base + grp;
+      const bool act = ci < nuniq;
+      int k = 0, tok = 0, lr = b;
+      if (act) {
+        if (!shared0) {
+          while (s_pre[k + 1] <= ci) ++k;
+          lr = row0 + k;
+        }
+        tok = tr.child_tok[tr.child_off[st.node[row0 + k]] + (ci - s_pre[k])];
+      }
+      float acc = 0.f;
+      if (act) {
+        const bf16* hp = hd + (size_t)lr * d + sub * per;
+        const bf16* ep = emb + (size_t)tok * d + sub * per;
+        for (int i = 0; i < per; i += 8) {
+          const bf16x8 hv = ld_global_b128(hp + i), ev = ld_global_b128(ep + i);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc += (float)hv[e] * (float)ev[e];
+        }
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      if (act && sub == 0) {
+        if (shared0) {
+          s_log[ci] = acc;
+        } else {
+          const float sc = (acc - lse[lr]) + st.beam_scores[lr];
+          keys[ci] = ((unsigned long long)f2ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(k * V + tok));
+        }
+      }
+    }
+    if (shared0) {
+      __syncthreads();
+      const int cnt0 = s_pre[1];
+      const int off0 = cnt0 > 0 ? tr.child_off[st.node[row0]] : 0;
+      for (int ci = tid; ci < C; ci += 256) {
+        const int k = ci / cnt0, j = ci - k * cnt0;
+        const int tok = tr.child_tok[off0 + j];
+        const float sc = (s_log[j] - lse[b]) + st.beam_scores[row0 + k];
+        keys[ci] = ((unsigned long long)f2ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(k * V + tok));
+      }
+    }
+    __syncthreads();
+  }
+  if (!isdone && logits != nullptr) {
     // gather: log_softmax at the allowed tokens + running beam score
     for (int ci = tid; ci < NC; ci += 256) {
       unsigned long long key = 0ull;
@@ -158,6 +215,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
       keys[ci] = key;
     }
     __syncthreads();
+  }
+  if (!isdone) {
     // bitonic sort, descending
     for (int kk = 2; kk <= NC; kk <<= 1) {
       for (int j = kk >> 1; j > 0; j >>= 1) {
@@ -370,15 +429,16 @@ extern "C" int gram_beam_init(const gram_beam_state_t* st, const gram_trie_t* tr
   return 0;
 }
 
-extern "C" int gram_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, const float* lse, int V,
-                              int cur_len, int rows_per_user, void* stream) {
+static int launch_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, const float* lse, int V,
+                            int cur_len, int rows_per_user, const void* hd, const void* emb, int d, void* stream) {
   if (int e = check_state(st)) return e;
-  if (!tr || cur_len < 1 || cur_len >= st->Tmax || V < 2 || (rows_per_user != 1 && rows_per_user != st->K)) return GRAM_E_ARG;
+  if (!tr || !lse || cur_len < 1 || cur_len >= st->Tmax || V < 2 || (rows_per_user != 1 && rows_per_user != st->K)) return GRAM_E_ARG;
+  if (!logits && (!hd || !emb || d < 64 || (d & 63))) return GRAM_E_ARG;
   long long need = (long long)st->K * tr->max_fanout;
   int nc = 64;
   while (nc < need) nc <<= 1;
-  const size_t smem = (size_t)nc * 8;
-  if (smem > 128 * 1024) return GRAM_E_ARG;
+  const size_t smem = (size_t)nc * 8 + ((size_t)tr->max_fanout * 4 + 15) / 16 * 16;
+  if (smem > 132 * 1024) return GRAM_E_ARG;
   static size_t attr_bytes = 0;
   if (smem > attr_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -387,9 +447,22 @@ extern "C" int gram_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr
     attr_bytes = smem;
   }
   gram_prof::Scope prof(GRAM_K_BEAM, (hipStream_t)stream, 0.0);
-  hipLaunchKernelGGL(beam_step_kernel, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc, rows_per_user);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc,
+                     rows_per_user, (const bf16*)hd, (const bf16*)emb, d);
   GRAM_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int gram_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, const float* lse, int V,
+                              int cur_len, int rows_per_user, void* stream) {
+  if (!logits) return GRAM_E_ARG;
+  return launch_beam_step(st, tr, logits, lse, V, cur_len, rows_per_user, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int gram_beam_step_sparse(const gram_beam_state_t* st, const gram_trie_t* tr, const void* hidden_bf16,
+                                     const void* lm_head_bf16, int d, const float* lse, int V, int cur_len, int rows_per_user,
+                                     void* stream) {
+  return launch_beam_step(st, tr, nullptr, lse, V, cur_len, rows_per_user, hidden_bf16, lm_head_bf16, d, stream);
 }
 
 extern "C" int gram_greedy_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, int V, int cur_len,

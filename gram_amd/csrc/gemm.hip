@@ -140,10 +140,12 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
       sm += __shfl_xor(sm, 16, 64);
       sm += __shfl_xor(sm, 32, 64);
       if (row_ok) {
+        if (ep.C) {  // logits == NULL: partials only (the beam kernel recomputes the few logits it needs)
 #pragma unroll
-        for (int i = 0; i < TNW; ++i) {
-          const int n = n0 + wn * 16 * TNW + i * 16 + 4 * g;
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n) = acc[i][j];
+          for (int i = 0; i < TNW; ++i) {
+            const int n = n0 + wn * 16 * TNW + i * 16 + 4 * g;
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n) = acc[i][j];
+          }
         }
         if (g == 0) {
           const int blk = (n0 >> 6) + wn;
@@ -730,7 +732,7 @@ extern "C" int gram_debug_set_gemm_variant(int v) {
 
 extern "C" int gram_gemm_bf16_lse(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int K, int lda,
                                   int ldc, void* stream) {
-  if (M < 1 || N % BN != 0 || K % BK != 0 || lda < K || (lda & 7) || !logits || !lse_part || (ldc & 3)) return GRAM_E_ARG;
+  if (M < 1 || N % BN != 0 || K % BK != 0 || lda < K || (lda & 7) || !lse_part || (logits && (ldc & 3))) return GRAM_E_ARG;
   EpiArgs ep{};
   ep.C = logits;
   ep.ldc = ldc;

@@ -173,7 +173,7 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   }
   const float scale = c.tie_word_embeddings ? 1.0f / sqrtf((float)d) : 1.f;  // gram_t5.py:249-252
   TRY(gram_rmsnorm_bf16(w.xd, c.dec_final_ln, w.hd, R, d, c.eps, scale, nullptr, 1, 1, st));
-  if (lse_part)  // log-softmax normaliser partials straight from the accumulators (no re-read of the logits)
+  if (lse_part)  // log-softmax normaliser partials straight from the accumulators; logits may be NULL (not stored)
     TRY(gram_gemm_bf16_lse(w.hd, c.lm_head_bf16, logits, lse_part, R, V, d, d, V, st));
   else
     TRY(gram_gemm_bf16(w.hd, c.lm_head_bf16, logits, R, V, d, d, V, GRAM_EPI_F32, nullptr, st));
@@ -283,9 +283,10 @@ extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, co
     // the cross-attention and the lm_head run on ONE row per user (HF runs K identical rows);
     // gram_beam_step reads that shared row and points every beam's slot-0 ancestor at it
     const int Kt = t == 0 ? 1 : K;
-    TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, Kt, B * K, max_length, t, w.logits, w.lse_part, stream));
+    // the [rows][V] logits are never written: LSE partials from the lm_head epilogue + sparse logits in the beam kernel
+    TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, Kt, B * K, max_length, t, nullptr, w.lse_part, stream));
     TRY(gram_lse_combine(w.lse_part, w.lse, B * Kt, m->d.vocab / 64, stream));
-    TRY(gram_beam_step(&w.beam, trie, w.logits, w.lse, m->d.vocab, t + 1, Kt, stream));
+    TRY(gram_beam_step_sparse(&w.beam, trie, w.hd, m->d.lm_head_bf16, m->d.d_model, w.lse, m->d.vocab, t + 1, Kt, stream));
   }
   TRY(gram_beam_finalize(&w.beam, nret, max_length, sequences, scores, w.width, stream));
   }

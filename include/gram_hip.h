@@ -64,7 +64,8 @@ int gram_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, i
 
 /* lm_head with the log-softmax normaliser fused: logits as GRAM_EPI_F32, plus for every row and every
  * 64-column block the pair (max, sum exp(x - max)) in lse_part f32 [M][N/64][2]; gram_lse_combine folds
- * them into lse[M] = log sum_v exp(logits[m][v]) without re-reading the logits (gram_row_lse does). */
+ * them into lse[M] = log sum_v exp(logits[m][v]) without re-reading the logits (gram_row_lse does).
+ * logits may be NULL: then only the partials are produced (see gram_beam_step_sparse). */
 int gram_gemm_bf16_lse(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int K, int lda,
                        int ldc, void* stream);
 int gram_lse_combine(const float* lse_part, float* lse, int M, int nblk, void* stream);
@@ -151,6 +152,13 @@ int gram_beam_init(const gram_beam_state_t* st_host, const gram_trie_t* trie_hos
  * one logits row and one self-attention cache row (step 0, where all beams are identical). */
 int gram_beam_step(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const float* logits,
                    const float* lse, int V, int cur_len, int rows_per_user, void* stream);
+
+/* Same step without a materialised logits tensor: the logits of the allowed tokens are recomputed inside the
+ * kernel as hidden[row] . lm_head[tok] (bf16 operands, fp32 accumulate), `lse` coming from
+ * gram_gemm_bf16_lse(logits = NULL) + gram_lse_combine.  hidden: bf16 [rows][d] (the lm_head A operand). */
+int gram_beam_step_sparse(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const void* hidden_bf16,
+                          const void* lm_head_bf16, int d, const float* lse, int V, int cur_len, int rows_per_user,
+                          void* stream);
 
 /* HF 4.26 greedy_search (generate with num_beams == 1; BASELINE configs[0]) on the same state with K = 1:
  * argmax of the RAW logits over the Trie children (first maximum), finished users emit pad; finalize copies

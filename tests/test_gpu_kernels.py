@@ -323,3 +323,51 @@ def test_greedy_step_bit_exact_vs_oracle(G):
     torch.cuda.synchronize()
     assert int(width[0]) == ref.shape[1]
     assert seqs[:, : ref.shape[1]].cpu().tolist() == ref.tolist()
+
+
+def test_beam_step_sparse_equals_dense(G):
+    """gram_beam_step_sparse (logits of the allowed tokens recomputed in the kernel from hidden . lm_head, LSE from
+    the fused lm_head epilogue, logits never stored) selects exactly what the dense path selects."""
+    import os
+    from gram_amd import _lib
+    from gram_amd.utils import generation_trie as gt
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tries.npz"))
+    cands = [[int(x) for x in r if x >= 0] for r in z["Toys_cands"]]
+    flat = gt.FlatTrie(gt.Trie(cands))
+    B, K, V, d = 5, 20, 32128, 768
+    R = B * K
+    max_length = max(len(c) for c in cands)
+    g = torch.Generator().manual_seed(3)
+    emb = G.bf(torch.randn(V, d, generator=g))
+    L_ = G.lib()
+    results = []
+    for mode in ("dense", "sparse"):
+        g2 = torch.Generator().manual_seed(17)
+        st, keep = G.make_beam_state(B, K, max_length)
+        ctrie, keep2 = flat.to_device(torch.device(G.DEV))
+        _lib.check(L_.gram_beam_init(C.byref(st), C.byref(ctrie), 0, G.stream()), "init")
+        for t in range(max_length - 1):
+            rows = B if t == 0 else R
+            rpu = 1 if t == 0 else K
+            h = G.bf(torch.randn(rows, d, generator=g2) * d ** -0.5 * 3)
+            part = torch.empty(rows, V // 64, 2, dtype=torch.float32, device=G.DEV)
+            lse = torch.empty(rows, dtype=torch.float32, device=G.DEV)
+            if mode == "dense":
+                logits = torch.empty(rows, V, dtype=torch.float32, device=G.DEV)
+                _lib.check(L_.gram_gemm_bf16_lse(G.p(h), G.p(emb), G.p(logits), G.p(part), rows, V, d, d, V, G.stream()), "gemm")
+                _lib.check(L_.gram_lse_combine(G.p(part), G.p(lse), rows, V // 64, G.stream()), "lse")
+                _lib.check(L_.gram_beam_step(C.byref(st), C.byref(ctrie), G.p(logits), G.p(lse), V, t + 1, rpu, G.stream()), "step")
+            else:
+                _lib.check(L_.gram_gemm_bf16_lse(G.p(h), G.p(emb), None, G.p(part), rows, V, d, d, V, G.stream()), "gemm")
+                _lib.check(L_.gram_lse_combine(G.p(part), G.p(lse), rows, V // 64, G.stream()), "lse")
+                _lib.check(L_.gram_beam_step_sparse(C.byref(st), C.byref(ctrie), G.p(h), G.p(emb), d, G.p(lse), V, t + 1, rpu, G.stream()),
+                           "step_sparse")
+        seqs = torch.empty(B * K, max_length, dtype=torch.int64, device=G.DEV)
+        scores = torch.empty(B * K, dtype=torch.float32, device=G.DEV)
+        width = torch.zeros(4, dtype=torch.int32, device=G.DEV)
+        _lib.check(L_.gram_beam_finalize(C.byref(st), K, max_length, G.p(seqs), G.p(scores), G.p(width), G.stream()), "fin")
+        torch.cuda.synchronize()
+        assert int(keep["error"][0]) == 0
+        results.append((seqs.cpu(), scores.cpu()))
+    assert results[0][0].tolist() == results[1][0].tolist()
+    assert torch.allclose(results[0][1], results[1][1], atol=2e-5)
