@@ -40,11 +40,15 @@ class BeamState(C.Structure):
                 ("n_hyps", vp), ("hyp_score", vp), ("worst", vp), ("hyp_len", vp), ("hyp_tok", vp), ("error", vp)]
 
 
+class NormFusion(C.Structure):
+    _fields_ = [("xb_out", vp), ("ss_out", vp), ("ss_in", vp), ("nblk_in", i32), ("d", i32), ("eps", f32)]
+
+
 class ModelDesc(C.Structure):
     _fields_ = [
         ("vocab", i32), ("d_model", i32), ("d_ff", i32), ("n_heads", i32), ("n_enc_layers", i32),
         ("n_dec_layers", i32), ("max_passages", i32), ("tie_word_embeddings", i32),
-        ("use_position_embedding", i32), ("eps", f32),
+        ("use_position_embedding", i32), ("fold_norm", i32), ("eps", f32),
         ("embed_f32", vp), ("lm_head_bf16", vp), ("pos_emb_f32", vp), ("enc_bias_f32", vp), ("dec_bias_f32", vp),
         ("enc_final_ln", vp), ("dec_final_ln", vp),
         ("enc_ln1", C.POINTER(vp)), ("enc_wqkv", C.POINTER(vp)), ("enc_wo", C.POINTER(vp)),
@@ -60,6 +64,9 @@ class ModelDesc(C.Structure):
 SIGNATURES = {
     "gram_abi_version": (C.c_int, []),
     "gram_gemm_bf16": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KVBank), vp]),
+    "gram_gemm_bf16_ex": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KVBank), C.POINTER(NormFusion), vp]),
+    "gram_row_rscale": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
+    "gram_embed_ex": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "gram_gemm_bf16_lse": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "gram_lse_combine": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "gram_embed_i64": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),

@@ -46,6 +46,12 @@ struct EpiArgs {
   int ldc;
   float* lse_part;  // GRAM_EPI_F32_LSE: [M][N/64][2]
   int lse_nblk;
+  // T5LayerNorm folding (gram_norm_fusion_t)
+  bf16* xb_out;        // producer: bf16 copy of the updated residual
+  float* ss_out;       // producer: [M][N/64] partial sums of squares
+  const float* ss_in;  // consumer: [M][ss_nblk] partials of A's rows
+  int ss_nblk, ss_out_nblk;
+  float inv_d, eps;
   // KV bank
   bf16* bank_k;
   bf16* bank_vt;
@@ -85,6 +91,33 @@ __device__ __forceinline__ void compute_tile(const char* sa, const char* sw, int
 // bf16 outputs: a lane owns 4 consecutive columns (8 B) of two adjacent n-tiles; lanes g and g^1
 // swap halves (one cross-lane exchange per tile pair) so that every lane issues ONE 16-byte store
 // per tile pair instead of two 8-byte ones -- the store tail of these K=768 GEMMs is issue-bound.
+// consumer side of the folded T5LayerNorm: 1/rms of row m of A from the producer's per-64-column partial sums
+// of squares, added in a fixed order (deterministic)
+__device__ __forceinline__ float row_rscale(const EpiArgs& ep, int m) {
+  if (!ep.ss_in) return 1.f;
+  if (ep.ss_nblk == 0) return ep.ss_in[m];  // already 1/rms (gram_row_rscale)
+  const float2* p = reinterpret_cast<const float2*>(ep.ss_in + (size_t)m * ep.ss_nblk);
+  float s = 0.f;
+  for (int i = 0; i < ep.ss_nblk / 2; ++i) {
+    const float2 v = p[i];
+    s += v.x + v.y;
+  }
+  return rsqrtf(s * ep.inv_d + ep.eps);
+}
+
+// The four output rows a lane owns (m = mbase + j*16 + r16).  Called BEFORE a tile's k-loop so that the
+// dependent loads of the partials are hidden behind the main loop instead of stalling the epilogue.
+__device__ __forceinline__ void load_row_scales(const EpiArgs& ep, int mbase, int r16, int M, float (&rs4)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rs4[j] = row_rscale(ep, min(mbase + j * 16 + r16, M - 1));
+  // pin the values HERE: without this hipcc sinks the dependent loads down to their use in the epilogue
+  // (registers are tight), where they stall every tile by ~3 us
+  if (ep.ss_in) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(rs4[j]));
+  }
+}
+
 __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
   bf16x4 o;
 #pragma unroll
@@ -94,15 +127,16 @@ __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
 
 template <int EPI, int TNW>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, int wm, int wn, int r16, int g, int M,
-                                         const EpiArgs& ep) {
+                                         const EpiArgs& ep, const float (&rs4)[4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + wm * 64 + j * 16 + r16;
     const bool row_ok = m < M;
     if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
+      const float rs = rs4[j];
 #pragma unroll
       for (int i = 0; i < TNW; i += 2) {
-        f32x4 v0 = acc[i][j], v1 = acc[i + 1][j];
+        f32x4 v0 = acc[i][j] * rs, v1 = acc[i + 1][j] * rs;
         if constexpr (EPI == GRAM_EPI_BF16_RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -154,15 +188,23 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
         }
       }
     } else {
-      if (!row_ok) continue;
+      // no early-out for rows past M: the sum-of-squares reduction below is a wave-wide shuffle
+      float ssq[TNW / 4];
+#pragma unroll
+      for (int q = 0; q < TNW / 4; ++q) ssq[q] = 0.f;
 #pragma unroll
       for (int i = 0; i < TNW; ++i) {
         const int n = n0 + wn * 16 * TNW + i * 16 + 4 * g;
         f32x4 v = acc[i][j];
+        if (row_ok) {
         if constexpr (EPI == GRAM_EPI_F32_ADD) {
           f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n);
-          f32x4 old = *p;
-          *p = old + v;
+          const f32x4 nv = *p + v;
+          *p = nv;
+          if (ep.xb_out) {
+            *reinterpret_cast<uint2*>(ep.xb_out + (size_t)m * ep.ldc + n) = pack_bf16x4(nv);
+            ssq[i / 4] += (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
+          }
         } else if constexpr (EPI == GRAM_EPI_F32) {
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n) = v;
         } else {  // GRAM_EPI_KV_BANK
@@ -178,6 +220,18 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) ep.bank_vt[(head * 64 + d + e) * ep.S + s] = (bf16)v[e];
+          }
+        }
+        }
+      }
+      if constexpr (EPI == GRAM_EPI_F32_ADD) {
+        if (ep.ss_out) {  // wave-uniform: per (row, 64-column block) partial sum of squares of the NEW residual
+#pragma unroll
+          for (int q = 0; q < TNW / 4; ++q) {
+            float t = ssq[q];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (g == 0 && row_ok) ep.ss_out[(size_t)m * ep.ss_out_nblk + ((n0 + wn * 16 * TNW) >> 6) + q] = t;
           }
         }
       }
@@ -236,6 +290,8 @@ __global__ __launch_bounds__(256, 2) void gemm_reg2_kernel(const bf16* __restric
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nkt = K / BK;
+  float rs4[4];
+  load_row_scales(ep, m0 + wm * 64, r16, M, rs4);
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -247,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_reg2_kernel(const bf16* __restric
     if (kt + 1 < nkt) store_tile(stage ^ 1);
     __syncthreads();
   }
-  epilogue<EPI, 4>(acc, m0, n0, wm, wn, r16, g, M, ep);
+  epilogue<EPI, 4>(acc, m0, n0, wm, wn, r16, g, M, ep, rs4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -308,6 +364,8 @@ __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nkt = K / BK;
+  float rs4[4];
+  load_row_scales(ep, m0 + wm * 64, r16, M, rs4);
   if constexpr (NST == 1) {
     for (int kt = 0; kt < nkt; ++kt) {
       dma(kt, 0);
@@ -325,7 +383,7 @@ __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void
       __syncthreads();  // drains DMA(kt+1) and fences the reads of stage st
     }
   }
-  epilogue<EPI, TNW>(acc, m0, n0, wm, wn, r16, g, M, ep);
+  epilogue<EPI, TNW>(acc, m0, n0, wm, wn, r16, g, M, ep, rs4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -384,6 +442,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16* __restric
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = K / SK;
+  float rs4[4];
+  load_row_scales(ep, m0 + wm * 64, r16, M, rs4);
   dma(0);
   if (nk > 1) dma(1);
   if (nk > 2) dma(2);
@@ -407,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16* __restric
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
   }
-  epilogue<EPI, 8>(acc, m0, n0, wm, wn, r16, g, M, ep);
+  epilogue<EPI, 8>(acc, m0, n0, wm, wn, r16, g, M, ep, rs4);
 }
 
 template <int EPI>
@@ -439,7 +499,7 @@ int launch_ring(const void* A, const void* W, int M, int N, int K, int lda, EpiA
 // conflict-free.  Wave-private: no workgroup barrier, only the wave's own LDS ordering.
 template <int EPI>
 __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[8][4], char* patch /* this wave's 8 KiB */, int m0, int n0, int wm,
-                                              int wn, int lane, int M, const EpiArgs& ep) {
+                                              int wn, int lane, int M, const EpiArgs& ep, const float (&rs4)[4]) {
   const int r16 = lane & 15, g = lane >> 4;
   if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
     // two passes of 32 rows x 128 cols bf16: patch[32][256 B], chunk c (16 B) stored at c ^ (row & 15)
@@ -449,9 +509,10 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[8][4], char* patch /*
       for (int jj = 0; jj < 2; ++jj) {
         const int j = pass * 2 + jj;
         const int row = jj * 16 + r16;
+        const float rs = rs4[j];  // folded T5LayerNorm (1 if unused)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          f32x4 v = acc[i][j];
+          f32x4 v = acc[i][j] * rs;
           if constexpr (EPI == GRAM_EPI_BF16_RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -486,10 +547,26 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[8][4], char* patch /*
         const int row = it * 2 + (lane >> 5), c = lane & 31;
         f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 512 + ((c ^ ((row & 15) << 1)) * 16));
         const int m = m0 + wm * 64 + j * 16 + row;
+        float ssq = 0.f;
         if (m < M) {
           f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4);
           if constexpr (EPI == GRAM_EPI_F32_ADD) val += *pc;
           *pc = val;
+          if constexpr (EPI == GRAM_EPI_F32_ADD) {
+            if (ep.xb_out) {
+              *reinterpret_cast<uint2*>(ep.xb_out + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4) = pack_bf16x4(val);
+              ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
+            }
+          }
+        }
+        if constexpr (EPI == GRAM_EPI_F32_ADD) {
+          if (ep.ss_out) {  // 16 lanes cover one 64-column block of one row
+            ssq += __shfl_xor(ssq, 1, 64);
+            ssq += __shfl_xor(ssq, 2, 64);
+            ssq += __shfl_xor(ssq, 4, 64);
+            ssq += __shfl_xor(ssq, 8, 64);
+            if ((c & 15) == 0 && m < M) ep.ss_out[(size_t)m * ep.ss_out_nblk + ((n0 + wn * 128) >> 6) + (c >> 4)] = ssq;
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -582,6 +659,8 @@ __global__ __launch_bounds__(512, 2) void gemm_il_kernel(const bf16* __restrict_
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float rs4[4];
+    load_row_scales(ep, m0 + wm * 64, r16, M, rs4);  // consumed by the epilogue; latency hidden by the k-loop
     __syncthreads();  // stage 0 of this tile landed (and the previous tile's stores are issued/drained)
     for (int kt = 0; kt < nkt; ++kt) {
       const int st = kt & 1;
@@ -610,12 +689,12 @@ __global__ __launch_bounds__(512, 2) void gemm_il_kernel(const bf16* __restrict_
         for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
       if (keep == 123.456f) reinterpret_cast<float*>(ep.C)[0] = keep;
     } else if constexpr (ABL == 4) {  // ablation: same stores, but always into this workgroup's first tile (cache-resident)
-      epilogue<EPI, 8>(acc, (slot / ntn) * TB, (slot % ntn) * TB, wm, wn, r16, g, M, ep);
+      epilogue<EPI, 8>(acc, (slot / ntn) * TB, (slot % ntn) * TB, wm, wn, r16, g, M, ep, rs4);
     } else if constexpr (EPI == GRAM_EPI_KV_BANK) {
-      epilogue<EPI, 8>(acc, cur_m0, cur_n0, wm, wn, r16, g, M, ep);
+      epilogue<EPI, 8>(acc, cur_m0, cur_n0, wm, wn, r16, g, M, ep, rs4);
     } else {
       // stage 1 is idle here (the next tile's first DMA went to stage 0): 8 waves x 8 KiB patches
-      epilogue_rows<EPI>(acc, smem + STAGE + wave * 8192, cur_m0, cur_n0, wm, wn, lane, M, ep);
+      epilogue_rows<EPI>(acc, smem + STAGE + wave * 8192, cur_m0, cur_n0, wm, wn, lane, M, ep, rs4);
     }
   }
 }
@@ -743,11 +822,32 @@ extern "C" int gram_gemm_bf16_lse(const void* A, const void* W, float* logits, f
 
 extern "C" int gram_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, int epilogue,
                               const gram_kv_bank_t* bank, void* stream) {
+  return gram_gemm_bf16_ex(A, W, C, M, N, K, lda, ldc, epilogue, bank, nullptr, stream);
+}
+
+extern "C" int gram_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, int epilogue,
+                                 const gram_kv_bank_t* bank, const gram_norm_fusion_t* nf, void* stream) {
   if (M < 1 || N % BN != 0 || K % BK != 0 || lda < K || (lda & 7)) return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   EpiArgs ep{};
   ep.C = C;
   ep.ldc = ldc;
+  if (nf) {
+    if (epilogue == GRAM_EPI_F32_ADD) {
+      if ((nf->xb_out == nullptr) != (nf->ss_out == nullptr)) return GRAM_E_ARG;
+      ep.xb_out = (bf16*)nf->xb_out;
+      ep.ss_out = nf->ss_out;
+      ep.ss_out_nblk = N / 64;
+    } else if (epilogue == GRAM_EPI_BF16 || epilogue == GRAM_EPI_BF16_RELU) {
+      if (nf->ss_in && nf->nblk_in != 0 && (nf->nblk_in < 2 || (nf->nblk_in & 1) || nf->d < 64)) return GRAM_E_ARG;
+      ep.ss_in = nf->ss_in;
+      ep.ss_nblk = nf->nblk_in;
+      ep.inv_d = 1.0f / (float)nf->d;
+      ep.eps = nf->eps;
+    } else if (nf->xb_out || nf->ss_out || nf->ss_in) {
+      return GRAM_E_ARG;
+    }
+  }
   switch (epilogue) {
     case GRAM_EPI_BF16:
       if (!C || (ldc & 7)) return GRAM_E_ARG;  // 16-byte row-aligned bf16 stores

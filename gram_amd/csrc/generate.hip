@@ -42,6 +42,8 @@ struct Workspace {
   bf16* qkv;        // [Me][3*inner]
   bf16* attn;       // [Me][inner]
   bf16* u;          // [Me][d_ff]
+  float* ss;        // [Me][d/64]  folded-norm partial sums of squares
+  float* rs;        // [Me]        1/rms per row
   // fused bank
   bf16* bank_k;     // [layers][B][H][S][64]
   bf16* bank_vt;    // [layers][B][H][64][S]
@@ -52,6 +54,8 @@ struct Workspace {
   bf16* attnd;      // [R][inner]
   bf16* qx;         // [R][inner]
   bf16* ud;         // [R][d_ff]
+  float* ssd;       // [R][d/64]
+  float* rsd;       // [R]
   bf16* kcache;     // [layers][Tmax][R][inner]
   bf16* vcache;
   float* logits;    // [R][V]
@@ -74,6 +78,8 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   w.qkv = cv.take<bf16>(Me * 3 * inner);
   w.attn = cv.take<bf16>(Me * inner);
   w.u = cv.take<bf16>(Me * F);
+  w.ss = cv.take<float>(Me * (d / 64));
+  w.rs = cv.take<float>(Me);
   w.bank_k = cv.take<bf16>(nl * B * c.n_heads * S * 64);
   w.bank_vt = cv.take<bf16>(nl * B * c.n_heads * S * 64);
   w.xd = cv.take<float>(R * d);
@@ -82,6 +88,8 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   w.attnd = cv.take<bf16>(R * inner);
   w.qx = cv.take<bf16>(R * inner);
   w.ud = cv.take<bf16>(R * F);
+  w.ssd = cv.take<float>(R * (d / 64));
+  w.rsd = cv.take<float>(R);
   w.kcache = cv.take<bf16>(nl * Tmax * R * inner);
   w.vcache = cv.take<bf16>(nl * Tmax * R * inner);
   w.logits = cv.take<float>(R * V);
@@ -128,6 +136,22 @@ int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const ui
   const gram_model_desc_t& c = m->d;
   const int d = c.d_model, inner = c.n_heads * 64, F = c.d_ff, H = c.n_heads;
   const int Me = B * N * L, P = B * N;
+  if (c.fold_norm) {
+    // T5LayerNorm folded into the GEMMs around it (gram_norm_fusion_t): w.h holds xb = bf16(x), w.ss the
+    // per-row sum-of-squares partials; both are refreshed by every residual GEMM's epilogue
+    const gram_norm_fusion_t produce{w.h, w.ss, nullptr, 0, 0, 0.f};
+    const gram_norm_fusion_t consume{nullptr, nullptr, w.rs, 0, d, c.eps};  // 1/rms precomputed per row (one tiny kernel per norm)
+    TRY(gram_embed_ex(c.embed_f32, ids, 1, w.x, w.h, w.ss, d / 64, Me, d, st));
+    for (int i = 0; i < c.n_enc_layers; ++i) {
+      TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
+      TRY(gram_gemm_bf16_ex(w.h, m->enc_wqkv[i], w.qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
+      TRY(gram_enc_self_attn(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, st));
+      TRY(gram_gemm_bf16_ex(w.attn, m->enc_wo[i], w.x, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
+      TRY(gram_gemm_bf16_ex(w.h, m->enc_wi[i], w.u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
+      TRY(gram_gemm_bf16_ex(w.u, m->enc_wo2[i], w.x, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+    }
+  } else {
   TRY(gram_embed_i64(c.embed_f32, ids, w.x, Me, d, st));
   for (int i = 0; i < c.n_enc_layers; ++i) {
     TRY(gram_rmsnorm_bf16(w.x, m->enc_ln1[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, st));
@@ -137,6 +161,7 @@ int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const ui
     TRY(gram_rmsnorm_bf16(w.x, m->enc_ln2[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, st));
     TRY(gram_gemm_bf16(w.h, m->enc_wi[i], w.u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, st));
     TRY(gram_gemm_bf16(w.u, m->enc_wo2[i], w.x, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, st));
+  }
   }
   // final norm + per-passage position embedding = the late fusion (gram.py:238-255); the
   // (B*N, L, d) -> (B, N*L, d) view is free: rows are already user-major.
@@ -156,6 +181,25 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   const int R = B * K, S = N * L;
   const size_t bank_layer = (size_t)B * H * S * 64;
   const size_t cache_layer = (size_t)Tmax * R_cache * inner;
+  if (c.fold_norm) {
+    const gram_norm_fusion_t produce{w.hd, w.ssd, nullptr, 0, 0, 0.f};
+    const gram_norm_fusion_t consume{nullptr, nullptr, w.rsd, 0, d, c.eps};
+    TRY(gram_embed_ex(c.embed_f32, tokens, 0, w.xd, w.hd, w.ssd, d / 64, R, d, st));
+    for (int i = 0; i < c.n_dec_layers; ++i) {
+      TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      TRY(gram_gemm_bf16_ex(w.hd, m->dec_wqkv[i], w.qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
+      TRY(gram_dec_self_attn(w.qkvd, w.kcache + i * cache_layer, w.vcache + i * cache_layer, anc, c.dec_bias_f32, w.attnd, R, H,
+                             t, Tmax, st));
+      TRY(gram_gemm_bf16_ex(w.attnd, m->dec_wo[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      TRY(gram_gemm_bf16_ex(w.hd, m->dec_wq_x[i], w.qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, &consume, st));
+      TRY(gram_cross_attn_decode(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd, B, K, H, S, st));
+      TRY(gram_gemm_bf16_ex(w.attnd, m->dec_wo_x[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      TRY(gram_gemm_bf16_ex(w.hd, m->dec_wi[i], w.ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
+      TRY(gram_gemm_bf16_ex(w.ud, m->dec_wo2[i], w.xd, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+    }
+  } else {
   TRY(gram_embed_i32(c.embed_f32, tokens, w.xd, R, d, st));
   for (int i = 0; i < c.n_dec_layers; ++i) {
     TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln1[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
@@ -170,6 +214,7 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
     TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln3[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
     TRY(gram_gemm_bf16(w.hd, m->dec_wi[i], w.ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, st));
     TRY(gram_gemm_bf16(w.ud, m->dec_wo2[i], w.xd, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, st));
+  }
   }
   const float scale = c.tie_word_embeddings ? 1.0f / sqrtf((float)d) : 1.f;  // gram_t5.py:249-252
   TRY(gram_rmsnorm_bf16(w.xd, c.dec_final_ln, w.hd, R, d, c.eps, scale, nullptr, 1, 1, st));

@@ -16,6 +16,31 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ ta
   for (int i = lane; i < d / 4; i += 64) dst[i] = src[i];
 }
 
+// embed_tokens for the folded-norm path: x (f32) + xb = bf16(x) + the row's sum of squares in ss[row][0]
+template <typename IdT>
+__global__ __launch_bounds__(256) void embed_ex_kernel(const float* __restrict__ table, const IdT* __restrict__ ids,
+                                                       float* __restrict__ x, bf16* __restrict__ xb, float* __restrict__ ss,
+                                                       int nblk, int rows, int d) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const f32x4* src = reinterpret_cast<const f32x4*>(table + (size_t)ids[row] * d);
+  f32x4* dst = reinterpret_cast<f32x4*>(x + (size_t)row * d);
+  bf16x4* dstb = reinterpret_cast<bf16x4*>(xb + (size_t)row * d);
+  float s = 0.f;
+  for (int i = lane; i < d / 4; i += 64) {
+    const f32x4 v = src[i];
+    dst[i] = v;
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+    dstb[i] = o;
+    s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  s = wave_sum(s);
+  if (lane < nblk) ss[(size_t)row * nblk + lane] = lane == 0 ? s : 0.f;
+}
+
 // T5LayerNorm (gram_t5_modeling.py:262-276): fp32 variance, no mean subtraction, no bias.
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       bf16* __restrict__ out, int rows, int d, float eps, float scale,
@@ -106,12 +131,47 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(const float* __restric
   if (lane == 0) lse[row] = wm + logf(s);
 }
 
+// 1/rms per row from the residual GEMM's partial sums of squares (fixed summation order)
+__global__ __launch_bounds__(256) void row_rscale_kernel(const float* __restrict__ ss, float* __restrict__ rs, int M, int nblk,
+                                                         float inv_d, float eps) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float2* p = reinterpret_cast<const float2*>(ss + (size_t)m * nblk);
+  float s = 0.f;
+  for (int i = 0; i < nblk / 2; ++i) {
+    const float2 v = p[i];
+    s += v.x + v.y;
+  }
+  rs[m] = rsqrtf(s * inv_d + eps);
+}
+
 }  // namespace
 
+extern "C" int gram_row_rscale(const float* ss, float* rs, int M, int nblk, int d, float eps, void* stream) {
+  if (M < 1 || nblk < 2 || (nblk & 1) || d < 64) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, 4.0 * M * (nblk + 1));
+  hipLaunchKernelGGL(row_rscale_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, ss, rs, M, nblk, 1.0f / (float)d, eps);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int gram_lse_combine(const float* lse_part, float* lse, int M, int nblk, void* stream) {
   if (M < 1 || nblk < 1) return GRAM_E_ARG;
   gram_prof::Scope prof(GRAM_K_LSE, (hipStream_t)stream, 8.0 * M * nblk);
   hipLaunchKernelGGL(lse_combine_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, lse_part, lse, M, nblk);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gram_embed_ex(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk,
+                             int rows, int d, void* stream) {
+  if (rows < 1 || (d & 3) || !xb || !ss || nblk < 1 || nblk > 64) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, 10.0 * rows * d);
+  if (ids_are_i64)
+    hipLaunchKernelGGL(embed_ex_kernel<int64_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, (const int64_t*)ids,
+                       x, (bf16*)xb, ss, nblk, rows, d);
+  else
+    hipLaunchKernelGGL(embed_ex_kernel<int32_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, (const int32_t*)ids,
+                       x, (bf16*)xb, ss, nblk, rows, d);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

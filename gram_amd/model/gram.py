@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Callable, Dict, Optional
 
 import torch
@@ -236,8 +237,18 @@ class GRAM(nn.Module):
             keep.append(arr)
             return C.cast(arr, C.POINTER(C.c_void_p))
 
-        def qkv(prefix):
-            return b16(torch.cat([sd[prefix + ".q.weight"], sd[prefix + ".k.weight"], sd[prefix + ".v.weight"]], 0))
+        # T5LayerNorm folding (gram_norm_fusion_t): the gain g of the norm in front of a Linear is folded into
+        # that Linear's columns (W[n][k] * g[k], in fp32, then one bf16 rounding); the 1/rms factor is applied
+        # per row in the GEMM epilogue.  GRAM_FOLD_NORM=0 keeps the separate norm kernels (A/B, debugging).
+        fold = os.environ.get("GRAM_FOLD_NORM", "1") != "0"
+
+        def lin(wname, gname):
+            w = sd[wname].to(dev, torch.float32)
+            return b16(w * sd[gname].to(dev, torch.float32)[None, :]) if fold else b16(w)
+
+        def qkv(prefix, gname):
+            w = torch.cat([sd[prefix + ".q.weight"], sd[prefix + ".k.weight"], sd[prefix + ".v.weight"]], 0).to(dev, torch.float32)
+            return b16(w * sd[gname].to(dev, torch.float32)[None, :]) if fold else b16(w)
 
         # relative-bias tables: encoder [H][255] by (key - query + 127), decoder [H][32] by distance
         nb, md = c.relative_attention_num_buckets, c.relative_attention_max_distance
@@ -257,26 +268,26 @@ class GRAM(nn.Module):
         desc = _lib.ModelDesc(
             vocab=c.vocab_size, d_model=c.d_model, d_ff=c.d_ff, n_heads=H, n_enc_layers=ne, n_dec_layers=nd,
             max_passages=self.max_item_num + 1, tie_word_embeddings=int(bool(getattr(c, "tie_word_embeddings", True))),
-            use_position_embedding=int(self.use_position_embedding), eps=float(c.layer_norm_epsilon),
+            use_position_embedding=int(self.use_position_embedding), fold_norm=int(fold), eps=float(c.layer_norm_epsilon),
             embed_f32=f32(sd["shared.weight"]), lm_head_bf16=b16(sd["lm_head.weight"]),
             pos_emb_f32=f32(sd["position_embedding.weight"]) if self.use_position_embedding else None,
             enc_bias_f32=f32(enc_bias), dec_bias_f32=f32(dec_bias),
             enc_final_ln=f32(sd["encoder.encoder.final_layer_norm.weight"]),
             dec_final_ln=f32(sd["decoder.final_layer_norm.weight"]),
             enc_ln1=ptr_array([f32(sd[e.format(i) + ".0.layer_norm.weight"]) for i in range(ne)]),
-            enc_wqkv=ptr_array([qkv(e.format(i) + ".0.SelfAttention") for i in range(ne)]),
+            enc_wqkv=ptr_array([qkv(e.format(i) + ".0.SelfAttention", e.format(i) + ".0.layer_norm.weight") for i in range(ne)]),
             enc_wo=ptr_array([b16(sd[e.format(i) + ".0.SelfAttention.o.weight"]) for i in range(ne)]),
             enc_ln2=ptr_array([f32(sd[e.format(i) + ".1.layer_norm.weight"]) for i in range(ne)]),
-            enc_wi=ptr_array([b16(sd[e.format(i) + ".1.DenseReluDense.wi.weight"]) for i in range(ne)]),
+            enc_wi=ptr_array([lin(e.format(i) + ".1.DenseReluDense.wi.weight", e.format(i) + ".1.layer_norm.weight") for i in range(ne)]),
             enc_wo2=ptr_array([b16(sd[e.format(i) + ".1.DenseReluDense.wo.weight"]) for i in range(ne)]),
             dec_ln1=ptr_array([f32(sd[dd.format(i) + ".0.layer_norm.weight"]) for i in range(nd)]),
-            dec_wqkv=ptr_array([qkv(dd.format(i) + ".0.SelfAttention") for i in range(nd)]),
+            dec_wqkv=ptr_array([qkv(dd.format(i) + ".0.SelfAttention", dd.format(i) + ".0.layer_norm.weight") for i in range(nd)]),
             dec_wo=ptr_array([b16(sd[dd.format(i) + ".0.SelfAttention.o.weight"]) for i in range(nd)]),
             dec_ln2=ptr_array([f32(sd[dd.format(i) + ".1.layer_norm.weight"]) for i in range(nd)]),
-            dec_wq_x=ptr_array([b16(sd[dd.format(i) + ".1.EncDecAttention.q.weight"]) for i in range(nd)]),
+            dec_wq_x=ptr_array([lin(dd.format(i) + ".1.EncDecAttention.q.weight", dd.format(i) + ".1.layer_norm.weight") for i in range(nd)]),
             dec_wo_x=ptr_array([b16(sd[dd.format(i) + ".1.EncDecAttention.o.weight"]) for i in range(nd)]),
             dec_ln3=ptr_array([f32(sd[dd.format(i) + ".2.layer_norm.weight"]) for i in range(nd)]),
-            dec_wi=ptr_array([b16(sd[dd.format(i) + ".2.DenseReluDense.wi.weight"]) for i in range(nd)]),
+            dec_wi=ptr_array([lin(dd.format(i) + ".2.DenseReluDense.wi.weight", dd.format(i) + ".2.layer_norm.weight") for i in range(nd)]),
             dec_wo2=ptr_array([b16(sd[dd.format(i) + ".2.DenseReluDense.wo.weight"]) for i in range(nd)]),
             dec_wkv_x_all=b16(wkv_all),
         )

@@ -62,6 +62,28 @@ typedef struct {
 int gram_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc,
                    int epilogue, const gram_kv_bank_t* bank_host, void* stream);
 
+/* T5LayerNorm folded into the GEMMs on either side of it (no separate norm pass over the residual stream):
+ *   producer (GRAM_EPI_F32_ADD):  besides x += acc it writes xb = bf16(x) and, per row and 64-column block,
+ *                                 the partial sum of squares ss_out[m][n/64] (deterministic: no atomics)
+ *   consumer (GRAM_EPI_BF16[_RELU]): A is xb, W has the norm gain folded in (W[n][k] * g[k]), and every output
+ *                                 row is scaled by rsqrt(sum_b ss_in[m][b] / d + eps) before ReLU / rounding,
+ * which equals Linear(T5LayerNorm(x)) (gram_t5_modeling.py:262-276 followed by :300-301 / :369-372). */
+typedef struct {
+  void* xb_out;        /* producer: bf16 [M][ldc] copy of the updated residual, or NULL            */
+  float* ss_out;       /* producer: f32 [M][N/64] partial sums of squares, or NULL                 */
+  const float* ss_in;  /* consumer: f32 [M][nblk_in] partials of the rows of A, or NULL            */
+  int32_t nblk_in;     /* consumer: d_model / 64, or 0 if ss_in already holds 1/rms per row        */
+  int32_t d;           /* consumer: d_model (the mean is over d elements)                          */
+  float eps;
+} gram_norm_fusion_t;
+int gram_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, int epilogue,
+                      const gram_kv_bank_t* bank_host, const gram_norm_fusion_t* nf_host, void* stream);
+/* rs[m] = rsqrt(sum_b ss[m][b] / d + eps); a consumer may take it directly with nblk_in = 0 (ss_in = rs). */
+int gram_row_rscale(const float* ss, float* rs, int M, int nblk, int d, float eps, void* stream);
+/* embed_tokens for the folded path: x (f32), xb = bf16(x), ss[m][0] = sum x^2 (other blocks 0). */
+int gram_embed_ex(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk, int rows,
+                  int d, void* stream);
+
 /* lm_head with the log-softmax normaliser fused: logits as GRAM_EPI_F32, plus for every row and every
  * 64-column block the pair (max, sum exp(x - max)) in lse_part f32 [M][N/64][2]; gram_lse_combine folds
  * them into lse[M] = log sum_v exp(logits[m][v]) without re-reading the logits (gram_row_lse does).
@@ -177,6 +199,7 @@ int gram_beam_finalize(const gram_beam_state_t* st_host, int nret, int max_lengt
 typedef struct {
   int32_t vocab, d_model, d_ff, n_heads, n_enc_layers, n_dec_layers, max_passages;
   int32_t tie_word_embeddings, use_position_embedding;
+  int32_t fold_norm; /* 1: enc_wqkv/enc_wi/dec_wqkv/dec_wq_x/dec_wi carry their layer-norm gain (gram_norm_fusion_t path) */
   float eps;
   const float* embed_f32;      /* [V][d]      shared.weight                                */
   const void* lm_head_bf16;    /* [V][d]      lm_head.weight                               */

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--stagger", type=int, default=-1)
+    ap.add_argument("--fuse", action="store_true", help="time the folded-layernorm epilogues (gram_norm_fusion_t)")
     a = ap.parse_args()
     lib = _lib.load()
     if a.stagger >= 0:
@@ -53,11 +54,22 @@ def main():
             err = (C[:256].float() - ref).abs().max().item()
             ok = err < (2e-3 if f32 else 3e-2)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            run = lambda: G.gemm(A, W, epi, C)
+            if a.fuse and epi != _lib.EPI_F32:
+                import ctypes as ct
+                if epi == _lib.EPI_F32_ADD:
+                    xb = torch.empty(M, N, dtype=torch.bfloat16, device=G.DEV)
+                    ss = torch.empty(M, N // 64, dtype=torch.float32, device=G.DEV)
+                    nf = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
+                else:
+                    ss = torch.rand(M, K // 64, dtype=torch.float32, device=G.DEV) + 1
+                    nf = _lib.NormFusion(None, None, ss.data_ptr(), K // 64, K, 1e-6)
+                run = lambda: _lib.check(lib.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(C), M, N, K, K, N, epi, None, ct.byref(nf), G.stream()), "ex")
             for _ in range(3):
-                G.gemm(A, W, epi, C)
+                run()
             s.record()
             for _ in range(a.iters):
-                G.gemm(A, W, epi, C)
+                run()
             e.record()
             torch.cuda.synchronize()
             us = s.elapsed_time(e) * 1e3 / a.iters

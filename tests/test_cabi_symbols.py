@@ -31,7 +31,7 @@ def test_abi_version_and_struct_sizes():
     assert ctypes.sizeof(_lib.KVBank) == 32
     assert ctypes.sizeof(_lib.Trie) == 40
     assert ctypes.sizeof(_lib.BeamState) == 24 + 12 * 8
-    assert ctypes.sizeof(_lib.ModelDesc) == 40 + 7 * 8 + 15 * 8 + 8
+    assert ctypes.sizeof(_lib.ModelDesc) == 48 + 7 * 8 + 15 * 8 + 8
 
 
 def test_argument_errors_without_gpu():

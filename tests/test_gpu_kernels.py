@@ -371,3 +371,47 @@ def test_beam_step_sparse_equals_dense(G):
         results.append((seqs.cpu(), scores.cpu()))
     assert results[0][0].tolist() == results[1][0].tolist()
     assert torch.allclose(results[0][1], results[1][1], atol=2e-5)
+
+
+@pytest.mark.parametrize("M", [300, 33000])  # 128x128 direct epilogue / persistent 256x256 row-contiguous epilogue
+def test_folded_layernorm_gemms(G, M):
+    """gram_norm_fusion_t: residual GEMM (producer: x += acc, xb = bf16(x), per-row sum-of-squares partials) followed by
+    a consumer GEMM on xb with the gain folded into W and 1/rms applied per row == Linear(T5LayerNorm(x))."""
+    from gram_amd import _lib
+    d, F = 768, 1024
+    g = torch.Generator().manual_seed(M)
+    x0 = (torch.randn(M, d, generator=g) * 2).to(G.DEV)
+    a = G.bf(torch.randn(M, d, generator=g))
+    Wo = G.bf(torch.randn(d, d, generator=g) * d ** -0.5)
+    gain = (1 + 0.1 * torch.randn(d, generator=g)).to(G.DEV)
+    Wi = torch.randn(F, d, generator=g).to(G.DEV) * d ** -0.5
+    Wi_folded = (Wi * gain[None, :]).to(torch.bfloat16).contiguous()
+    x = x0.clone()
+    xb = torch.zeros(M, d, dtype=torch.bfloat16, device=G.DEV)
+    ss = torch.full((M, d // 64), float("nan"), dtype=torch.float32, device=G.DEV)
+    L_ = G.lib()
+    prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
+    _lib.check(L_.gram_gemm_bf16_ex(G.p(a), G.p(Wo), G.p(x), M, d, d, d, d, _lib.EPI_F32_ADD, None, C.byref(prod), G.stream()), "producer")
+    x_ref = x0 + a.float() @ Wo.float().T
+    assert torch.allclose(x, x_ref, atol=2e-3, rtol=1e-4)
+    assert torch.equal(xb, x.to(torch.bfloat16))
+    assert torch.allclose(ss.sum(-1), (x * x).sum(-1), rtol=1e-5)
+    for epi, act in ((_lib.EPI_BF16, lambda t: t), (_lib.EPI_BF16_RELU, lambda t: t.clamp(min=0))):
+        y = torch.empty(M, F, dtype=torch.bfloat16, device=G.DEV)
+        cons = _lib.NormFusion(None, None, ss.data_ptr(), d // 64, d, 1e-6)
+        _lib.check(L_.gram_gemm_bf16_ex(G.p(xb), G.p(Wi_folded), G.p(y), M, F, d, d, F, epi, None, C.byref(cons), G.stream()), "consumer")
+        ref = act(O.rms_norm(x.cpu(), gain.cpu(), 1e-6) @ Wi.cpu().T)
+        # bf16 operands (x and g*W rounded once each) + bf16 output on O(1) values
+        assert torch.allclose(y.float().cpu(), ref, atol=4e-2, rtol=2e-2)
+        rel = (y.float().cpu() - ref).norm() / ref.norm()
+        assert rel < 6e-3, float(rel)
+    # embed_ex
+    V = 512
+    table = torch.randn(V, d, generator=g).to(G.DEV)
+    ids = torch.randint(0, V, (77,), generator=g).to(G.DEV)
+    xe = torch.empty(77, d, device=G.DEV)
+    xbe = torch.empty(77, d, dtype=torch.bfloat16, device=G.DEV)
+    sse = torch.empty(77, d // 64, device=G.DEV)
+    _lib.check(L_.gram_embed_ex(G.p(table), G.p(ids), 1, G.p(xe), G.p(xbe), G.p(sse), d // 64, 77, d, G.stream()), "embed_ex")
+    assert torch.equal(xe, table[ids]) and torch.equal(xbe, table[ids].to(torch.bfloat16))
+    assert torch.allclose(sse.sum(-1), (xe * xe).sum(-1), rtol=1e-5) and bool((sse[:, 1:] == 0).all())
