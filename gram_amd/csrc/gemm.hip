@@ -731,14 +731,13 @@ int launch_il(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
 //   lm_head (N = 32128, not a multiple of 256):  V_DMA_M256 783 > V_DMA 614
 //   M ~ 10240 (decoder):         V_DMA 475-832 > V_DMA_M256 418-801 > V_IL 299-696 (too few tiles per CU)
 int pick_variant(int M, int N, int K) {
-  (void)K;
   if (g_force_variant >= 0) return g_force_variant;
   const long tiles256 = (long)((M + 255) / 256) * (N / BN);
-  if (tiles256 >= 2048) {  // >= 8 workgroups of 256x128 per CU: the big-tile variants pay off
-    static const int big = getenv("GRAM_GEMM_BIG") ? atoi(getenv("GRAM_GEMM_BIG")) : V_IL;  // A/B hook
-    if (N % 256 == 0 && M >= 32768) return big;
-    return V_DMA_M256;
-  }
+  static const int big = getenv("GRAM_GEMM_BIG") ? atoi(getenv("GRAM_GEMM_BIG")) : V_IL;  // A/B hook
+  // persistent 256x256: needs >= ~2 tiles per CU to amortise its fill/drain; with a long K (FFN-wo, K = 4*d) it
+  // already wins at 480 tiles (M = 40960, N = 768: 230 us vs 277 us for the 128x128 variant)
+  if (N % 256 == 0 && M >= 32768 && (tiles256 >= 2048 || K >= 2048)) return big;
+  if (tiles256 >= 2048) return V_DMA_M256;
   return V_DMA;
 }
 
