@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--beams", type=int, default=20)
     ap.add_argument("--cpu-users", type=int, default=2, help="users in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--ragged", action="store_true",
+                    help="realistic batch: passage counts drawn from the dataset's histogram (padded to --passages), valid "
+                         "lengths U[32, L]; not the headline configuration")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL on ROCm)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: all ranks use cuda:0 (with --backend gloo; RCCL needs one GPU per rank)")
@@ -105,6 +108,14 @@ def main():
     ids = torch.randint(2, 32100, (B, N, L), generator=g)
     ids[:, :, -1] = 1
     mask = torch.ones(B, N, L, dtype=torch.bool)
+    if args.ragged:
+        hist = torch.tensor(z[f"{args.dataset}_npassage_hist"][: N + 1].astype("float64"))
+        hist[N] += float(z[f"{args.dataset}_npassage_hist"][N + 1:].sum())
+        hist[0] = 0
+        n_user = torch.multinomial(hist / hist.sum(), B, replacement=True, generator=g)
+        lens = torch.randint(32, L + 1, (B, N), generator=g)
+        mask = (torch.arange(L)[None, None, :] < lens[:, :, None]) & (torch.arange(N)[None, :, None] < n_user[:, None, None])
+        ids[~mask] = 0
     ids_d, mask_d = ids.to(dev), mask.to(dev)
 
     def step():
@@ -166,7 +177,7 @@ def main():
         "config": {
             "workload": f"{args.dataset} Trie ({len(cands)} items, T={max_length - 1}), {args.backbone}, "
                         f"{N} granularity passages x {L} tokens (S={N * L}), beam={K} top-{K}",
-            "users_per_step_per_gpu": B, "parallelism": f"dp{world} (users sharded, no data-path collective)",
+            "ragged": bool(args.ragged), "users_per_step_per_gpu": B, "parallelism": f"dp{world} (users sharded, no data-path collective)",
             "precision": "bf16 operands / fp32 accumulate, fp32 residual stream, softmax and scores",
         },
         "output_check": {"sequences_shape": list(out["sequences"].shape),

@@ -26,7 +26,8 @@ f32 = C.c_float
 
 
 class KVBank(C.Structure):
-    _fields_ = [("k", vp), ("vt", vp), ("n_layers", i32), ("B", i32), ("H", i32), ("S", i32)]
+    _fields_ = [("k", vp), ("vt", vp), ("n_layers", i32), ("B", i32), ("H", i32), ("S", i32), ("passage_map", vp), ("N", i32),
+                ("L", i32)]
 
 
 class Trie(C.Structure):
@@ -42,6 +43,10 @@ class BeamState(C.Structure):
 
 class NormFusion(C.Structure):
     _fields_ = [("xb_out", vp), ("ss_out", vp), ("ss_in", vp), ("nblk_in", i32), ("d", i32), ("eps", f32)]
+
+
+class Compaction(C.Structure):
+    _fields_ = [("n_active", i32), ("passage_map", vp), ("ids", vp), ("mask", vp)]
 
 
 class ModelDesc(C.Structure):
@@ -91,6 +96,9 @@ SIGNATURES = {
     "gram_prof_enable": (C.c_int, [C.c_uint32, C.c_int]),
     "gram_prof_reset": (C.c_int, []),
     "gram_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64)]),
+    "gram_rmsnorm_bf16_map": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, f32, f32, vp, C.c_int, C.c_int, vp, vp]),
+    "gram_generate_ex": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.POINTER(Trie),
+                                   C.POINTER(Compaction), vp, i64, vp, vp, C.POINTER(i32), vp]),
     "gram_generate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.POINTER(Trie),
                                 vp, i64, vp, vp, C.POINTER(i32), vp]),
 }

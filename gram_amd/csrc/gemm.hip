@@ -56,6 +56,8 @@ struct EpiArgs {
   bf16* bank_k;
   bf16* bank_vt;
   int S, H, B, inner;
+  const int32_t* pmap;  // compacted encoder rows: passage p = m / pL is flat passage pmap[p] = b*pN + n (NULL: identity)
+  int pL, pN;
 };
 
 // XCD-aware bijective remap of the 1-D workgroup id -> (m-tile, n-tile), n fastest.
@@ -208,7 +210,15 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
         } else if constexpr (EPI == GRAM_EPI_F32) {
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n) = v;
         } else {  // GRAM_EPI_KV_BANK
-          const int b = m / ep.S, s = m - b * ep.S;
+          int b, s;
+          if (ep.pmap) {
+            const int p = m / ep.pL, l = m - p * ep.pL, flat = ep.pmap[p];
+            b = flat / ep.pN;
+            s = (flat - b * ep.pN) * ep.pL + l;
+          } else {
+            b = m / ep.S;
+            s = m - b * ep.S;
+          }
           const int lw = n / ep.inner;  // layer*2 + which   (uniform per block: inner % 128 == 0)
           const int layer = lw >> 1, which = lw & 1;
           const int rem = n - lw * ep.inner;
@@ -863,14 +873,21 @@ extern "C" int gram_gemm_bf16_ex(const void* A, const void* W, void* C, int M, i
     case GRAM_EPI_KV_BANK: {
       if (!bank || !bank->k || !bank->vt) return GRAM_E_ARG;
       const int inner = bank->H * 64;
-      if (inner % BN != 0 || N != bank->n_layers * 2 * inner || M != bank->B * bank->S || bank->S % 16 != 0)
+      if (inner % BN != 0 || N != bank->n_layers * 2 * inner || bank->S % 16 != 0) return GRAM_E_ARG;
+      if (bank->passage_map) {
+        if (bank->L < 16 || bank->N < 1 || bank->N * bank->L != bank->S || M % bank->L != 0 || M > bank->B * bank->S) return GRAM_E_ARG;
+      } else if (M != bank->B * bank->S) {
         return GRAM_E_ARG;
+      }
       ep.bank_k = (bf16*)bank->k;
       ep.bank_vt = (bf16*)bank->vt;
       ep.S = bank->S;
       ep.H = bank->H;
       ep.B = bank->B;
       ep.inner = inner;
+      ep.pmap = bank->passage_map;
+      ep.pL = bank->L;
+      ep.pN = bank->N;
       return launch<GRAM_EPI_KV_BANK>(A, W, M, N, K, lda, ep, st);
     }
     default:

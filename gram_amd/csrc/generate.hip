@@ -132,10 +132,12 @@ int check_shapes(const gram_model* m, int B, int N, int L, int K, int Tmax) {
     if (e__) return e__;  \
   } while (0)
 
-int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const uint8_t* mask, int B, int N, int L, void* st) {
+// ids/mask: [P][L] for the P passages the encoder runs on (all B*N, or the active ones with their flat indices in pmap)
+int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const uint8_t* mask, int B, int N, int L, int P,
+           const int32_t* pmap, void* st) {
   const gram_model_desc_t& c = m->d;
   const int d = c.d_model, inner = c.n_heads * 64, F = c.d_ff, H = c.n_heads;
-  const int Me = B * N * L, P = B * N;
+  const int Me = P * L;
   if (c.fold_norm) {
     // T5LayerNorm folded into the GEMMs around it (gram_norm_fusion_t): w.h holds xb = bf16(x), w.ss the
     // per-row sum-of-squares partials; both are refreshed by every residual GEMM's epilogue
@@ -165,10 +167,10 @@ int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const ui
   }
   // final norm + per-passage position embedding = the late fusion (gram.py:238-255); the
   // (B*N, L, d) -> (B, N*L, d) view is free: rows are already user-major.
-  TRY(gram_rmsnorm_bf16(w.x, c.enc_final_ln, w.h, Me, d, c.eps, 1.f, c.use_position_embedding ? c.pos_emb_f32 : nullptr, N, L,
-                        st));
+  TRY(gram_rmsnorm_bf16_map(w.x, c.enc_final_ln, w.h, Me, d, c.eps, 1.f, c.use_position_embedding ? c.pos_emb_f32 : nullptr, N, L,
+                            pmap, st));
   // every decoder layer's cross K/V in ONE GEMM, scattered into the beam-shared bank
-  gram_kv_bank_t bank{w.bank_k, w.bank_vt, c.n_dec_layers, B, H, N * L};
+  gram_kv_bank_t bank{w.bank_k, w.bank_vt, c.n_dec_layers, B, H, N * L, pmap, N, L};
   TRY(gram_gemm_bf16(w.h, c.dec_wkv_x_all, nullptr, Me, c.n_dec_layers * 2 * inner, d, d, 0, GRAM_EPI_KV_BANK, &bank, st));
   return 0;
 }
@@ -284,7 +286,7 @@ extern "C" int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids
   TRY(check_shapes(m, B, N, L, K, max_length));
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
-  TRY(encode(m, w, input_ids, mask, B, N, L, stream));
+  TRY(encode(m, w, input_ids, mask, B, N, L, B * N, nullptr, stream));
   if (enc_out_bf16) {
     hipError_t e = hipMemcpyAsync(enc_out_bf16, w.h, (size_t)B * N * L * m->d.d_model * sizeof(bf16), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream);
@@ -306,13 +308,25 @@ extern "C" int gram_decode_step(const gram_model_t* m, const int32_t* tokens, co
 extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K,
                              int nret, int max_length, float length_penalty, const gram_trie_t* trie, void* workspace,
                              int64_t workspace_bytes, int64_t* sequences, float* scores, int32_t* width_host, void* stream) {
+  return gram_generate_ex(m, input_ids, mask, B, N, L, K, nret, max_length, length_penalty, trie, nullptr, workspace, workspace_bytes,
+                          sequences, scores, width_host, stream);
+}
+
+extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K,
+                                int nret, int max_length, float length_penalty, const gram_trie_t* trie,
+                                const gram_compaction_t* comp, void* workspace, int64_t workspace_bytes, int64_t* sequences,
+                                float* scores, int32_t* width_host, void* stream) {
   TRY(check_shapes(m, B, N, L, K, max_length));
+  if (comp && (comp->n_active < B || comp->n_active > B * N || !comp->passage_map || !comp->ids || !comp->mask)) return GRAM_E_ARG;
   if (!trie || nret < 1 || nret > K || !sequences || (!scores && K != 1)) return GRAM_E_ARG;
   if ((long long)K * trie->max_fanout > 16384) return GRAM_E_ARG;
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
   w.beam.length_penalty = length_penalty;
-  TRY(encode(m, w, input_ids, mask, B, N, L, stream));
+  if (comp)  // the encoder runs on the active passages only; padded ones leave their bank positions untouched (never read)
+    TRY(encode(m, w, comp->ids, comp->mask, B, N, L, comp->n_active, comp->passage_map, stream));
+  else
+    TRY(encode(m, w, input_ids, mask, B, N, L, B * N, nullptr, stream));
   TRY(gram_beam_init(&w.beam, trie, /*decoder_start_token_id=*/0, stream));
   if (K == 1) {  // HF: num_beams == 1 -> greedy_search (raw logits, no hypotheses, no scores)
     for (int t = 0; t + 1 < max_length; ++t) {

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void embed_ex_kernel(const float* __restrict__
 // T5LayerNorm (gram_t5_modeling.py:262-276): fp32 variance, no mean subtraction, no bias.
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       bf16* __restrict__ out, int rows, int d, float eps, float scale,
-                                                      const float* __restrict__ pos, int N, int L) {
+                                                      const float* __restrict__ pos, int N, int L,
+                                                      const int32_t* __restrict__ pmap) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -63,7 +64,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   ss = wave_sum(ss);
   const float rs = rsqrtf(ss / (float)d + eps);
   const f32x4* wr = reinterpret_cast<const f32x4*>(w);
-  const f32x4* pr = pos ? reinterpret_cast<const f32x4*>(pos + (size_t)((row / L) % N) * d) : nullptr;
+  // passage index of this row: row / L, or through the compaction map (flat index b*N + n)
+  const int pn = pos ? ((pmap ? pmap[row / L] : row / L) % N) : 0;
+  const f32x4* pr = pos ? reinterpret_cast<const f32x4*>(pos + (size_t)pn * d) : nullptr;
   bf16x4* o = reinterpret_cast<bf16x4*>(out + (size_t)row * d);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -192,6 +195,11 @@ extern "C" int gram_embed_i32(const float* table, const int32_t* ids, float* x, 
 }
 extern "C" int gram_rmsnorm_bf16(const float* x, const float* w, void* out, int rows, int d, float eps, float scale,
                                  const float* pos, int N, int L, void* stream) {
+  return gram_rmsnorm_bf16_map(x, w, out, rows, d, eps, scale, pos, N, L, nullptr, stream);
+}
+
+extern "C" int gram_rmsnorm_bf16_map(const float* x, const float* w, void* out, int rows, int d, float eps, float scale,
+                                     const float* pos, int N, int L, const int32_t* passage_map, void* stream) {
   if (rows < 1 || (d & 3) || d > 1024 || (pos && (N < 1 || L < 1))) return GRAM_E_ARG;
   if (!pos) {
     N = 1;
@@ -199,7 +207,7 @@ extern "C" int gram_rmsnorm_bf16(const float* x, const float* w, void* out, int 
   }
   gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, 6.0 * rows * d);
   hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)out, rows, d, eps,
-                     scale, pos, N, L);
+                     scale, pos, N, L, passage_map);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

@@ -358,6 +358,21 @@ class GRAM(nn.Module):
             ids = torch.nn.functional.pad(ids, (0, Lp - L))
             mask = torch.nn.functional.pad(mask, (0, Lp - L))
         ids, mask = ids.contiguous(), mask.contiguous()
+        # Ragged batches: the Collator pads every user to the batch's largest passage count with fully masked
+        # passages; gather the active ones so the encoder skips the rest (one 1-element D2H sync; the gathers are
+        # input plumbing).  GRAM_COMPACT=0 disables it.
+        comp = None
+        if os.environ.get("GRAM_COMPACT", "1") != "0" and N > 1:
+            active = mask.view(B * N, Lp).any(dim=1)
+            n_active = int(active.sum())
+            if n_active < B * N:
+                if int(active.view(B, N).any(dim=1).sum()) < B:
+                    raise ValueError("every user needs at least one passage with a valid token")
+                pidx = active.nonzero().squeeze(1)
+                c_ids = ids.view(B * N, Lp).index_select(0, pidx).contiguous()
+                c_mask = mask.view(B * N, Lp).index_select(0, pidx).contiguous()
+                c_map = pidx.to(torch.int32).contiguous()
+                comp = (_lib.Compaction(n_active, c_map.data_ptr(), c_ids.data_ptr(), c_mask.data_ptr()), (c_ids, c_mask, c_map))
         flat = self._flat_trie(prefix_allowed_tokens_fn)
         ctrie, _keep = flat.to_device(dev)
         ws = self._get_workspace(handle, B, N, Lp, K, int(max_length))
@@ -369,9 +384,10 @@ class GRAM(nn.Module):
         width = C.c_int32(0)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            rc = lib.gram_generate(handle, ids.data_ptr(), mask.data_ptr(), B, N, Lp, K, nret, int(max_length),
-                                   float(length_penalty), C.byref(ctrie), ws.data_ptr(), ws.numel(), seqs.data_ptr(),
-                                   scores.data_ptr() if scores is not None else None, C.byref(width), stream)
+            rc = lib.gram_generate_ex(handle, ids.data_ptr(), mask.data_ptr(), B, N, Lp, K, nret, int(max_length),
+                                      float(length_penalty), C.byref(ctrie), C.byref(comp[0]) if comp else None, ws.data_ptr(),
+                                      ws.numel(), seqs.data_ptr(), scores.data_ptr() if scores is not None else None,
+                                      C.byref(width), stream)
         _lib.check(rc, "gram_generate")
         seqs = seqs[:, : width.value]
         if not return_dict_in_generate:

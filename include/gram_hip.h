@@ -53,6 +53,10 @@ typedef struct {
   void* k;
   void* vt;
   int32_t n_layers, B, H, S;
+  /* optional compaction of fully padded passages: GEMM row m belongs to compact passage p = m / L, which is
+   * passage n = passage_map[p] % N of user b = passage_map[p] / N (S = N*L).  NULL = rows are b*S + s. */
+  const int32_t* passage_map;
+  int32_t N, L;
 } gram_kv_bank_t;
 
 /* C[M,N] (+)= A[M,K] @ W[N,K]^T, bf16 operands, fp32 accumulate on MFMA.
@@ -103,6 +107,9 @@ int gram_embed_i32(const float* table, const int32_t* ids, float* x, int rows, i
  * embedding of the late fusion (gram.py:238-249). */
 int gram_rmsnorm_bf16(const float* x, const float* w, void* out_bf16, int rows, int d, float eps,
                       float scale, const float* pos, int N, int L, void* stream);
+/* same, for compacted passages: the passage of row r is passage_map[r / L] % N (see gram_kv_bank_t) */
+int gram_rmsnorm_bf16_map(const float* x, const float* w, void* out_bf16, int rows, int d, float eps, float scale,
+                          const float* pos, int N, int L, const int32_t* passage_map, void* stream);
 
 /* Encoder self-attention for P passages of L tokens (T5Attention.forward, bidirectional,
  * gram_t5_modeling.py:479-631): unscaled QK^T + bucketed relative bias + key mask, fp32
@@ -263,6 +270,22 @@ int gram_generate(const gram_model_t* m, const int64_t* input_ids, const uint8_t
                   int K, int nret, int max_length, float length_penalty, const gram_trie_t* trie_host,
                   void* workspace, int64_t workspace_bytes, int64_t* sequences, float* scores,
                   int32_t* width_host, void* stream);
+
+/* Ragged batches: the Collator pads every user to the batch's largest passage count with fully masked passages
+ * (Collator.py:410-436); the encoder need not run on those.  The caller passes the n_active passages that have
+ * at least one valid token, gathered contiguously (ids/mask [n_active][L]), and their flat indices
+ * passage_map[p] = b*N + n (ascending).  `mask` stays the full (B,N,L) mask: the cross-attention skips the
+ * untouched bank positions of the padded passages.  Every user must keep >= 1 active passage. */
+typedef struct {
+  int32_t n_active;
+  const int32_t* passage_map; /* device, i32 [n_active] */
+  const int64_t* ids;         /* device, i64 [n_active][L] */
+  const uint8_t* mask;        /* device, u8  [n_active][L] */
+} gram_compaction_t;
+int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L,
+                     int K, int nret, int max_length, float length_penalty, const gram_trie_t* trie_host,
+                     const gram_compaction_t* compaction_host, void* workspace, int64_t workspace_bytes,
+                     int64_t* sequences, float* scores, int32_t* width_host, void* stream);
 
 /* ---- live per-kernel timing (bench.py) ------------------------------------------------ */
 enum gram_kernel_kind {

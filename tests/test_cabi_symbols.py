@@ -28,7 +28,7 @@ def test_abi_version_and_struct_sizes():
     lib = _lib.load()
     assert lib.gram_abi_version() == 1
     # field layout sanity (pointer + int32 packing as in the C header)
-    assert ctypes.sizeof(_lib.KVBank) == 32
+    assert ctypes.sizeof(_lib.KVBank) == 48
     assert ctypes.sizeof(_lib.Trie) == 40
     assert ctypes.sizeof(_lib.BeamState) == 24 + 12 * 8
     assert ctypes.sizeof(_lib.ModelDesc) == 48 + 7 * 8 + 15 * 8 + 8

@@ -129,3 +129,24 @@ def test_full_size_properties_and_batch_invariance(gpu):
     Lt = min(L, (Lt + 31) // 32 * 32)
     o4 = _generate(m, ids[:8, :, :Lt], mask[:8, :, :Lt], cands, K)
     assert torch.equal(o4["sequences_scores"].cpu(), scores[: 8 * K])
+
+
+def test_passage_compaction_is_result_neutral(gpu, monkeypatch):
+    """Ragged batch (users padded to N = 5 with fully masked passages): running the encoder on the active
+    passages only gives bit-identical sequences and scores, and the padded bank positions are never read
+    (they are poisoned with NaN-pattern garbage first)."""
+    oc, sd, m = _model(gpu, "small", 5)
+    cands = _trie_cands("Toys")
+    g = torch.Generator().manual_seed(21)
+    B, N, L, K = 12, 5, 64, 8  # the 'small' test model has max_item_num = 4
+    ids, mask = _realistic_inputs(g, B, N, L)
+    assert int(mask.any(-1).sum()) < B * N  # some passages are fully padded
+    monkeypatch.setenv("GRAM_COMPACT", "0")
+    full = _generate(m, ids, mask, cands, K)
+    f_seq, f_sc = full["sequences"].cpu(), full["sequences_scores"].cpu()
+    m._workspace.fill_(0xFF)  # bf16 0xFFFF = NaN: any read of an untouched bank position would poison the output
+    monkeypatch.setenv("GRAM_COMPACT", "1")
+    comp = _generate(m, ids, mask, cands, K)
+    assert torch.equal(comp["sequences"].cpu(), f_seq)
+    assert torch.equal(comp["sequences_scores"].cpu(), f_sc)
+    assert torch.isfinite(comp["sequences_scores"]).all()
