@@ -311,19 +311,16 @@ class GRAM(nn.Module):
             self._workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
         return self._workspace
 
-    def _flat_trie(self, fn: Callable) -> FlatTrie:
-        trie = None
+    @staticmethod
+    def _closure_trie(fn: Callable):
         for cell in getattr(fn, "__closure__", None) or ():
             obj = cell.cell_contents
             if hasattr(obj, "trie_dict") and hasattr(obj, "get"):
-                trie = obj
-                break
-        if trie is None:
-            raise NotImplementedError(
-                "prefix_allowed_tokens_fn must be the closure returned by "
-                "utils.generation_trie.prefix_allowed_tokens_fn(trie) (the only form the GRAM runners pass); "
-                "arbitrary Python callbacks would need one host round trip per beam per step"
-            )
+                return obj
+        return None
+
+    def _flat_trie(self, fn: Callable) -> FlatTrie:
+        trie = self._closure_trie(fn)
         key = id(trie)
         cached = self._tries.get(key)
         if cached is None or cached.n_sequences != len(trie):
@@ -358,6 +355,11 @@ class GRAM(nn.Module):
             ids = torch.nn.functional.pad(ids, (0, Lp - L))
             mask = torch.nn.functional.pad(mask, (0, Lp - L))
         ids, mask = ids.contiguous(), mask.contiguous()
+        if self._closure_trie(prefix_allowed_tokens_fn) is None:
+            if K == 1:
+                raise NotImplementedError("greedy search needs the Trie closure form of prefix_allowed_tokens_fn")
+            return self._generate_with_callback(ids, mask, B, N, Lp, K, nret, int(max_length), float(length_penalty),
+                                                prefix_allowed_tokens_fn, return_dict_in_generate)
         # Ragged batches: the Collator pads every user to the batch's largest passage count with fully masked
         # passages; gather the active ones so the encoder skips the rest (one 1-element D2H sync; the gathers are
         # input plumbing).  GRAM_COMPACT=0 disables it.
@@ -393,6 +395,72 @@ class GRAM(nn.Module):
         if not return_dict_in_generate:
             return seqs
         return GenerateOutput(sequences=seqs, sequences_scores=scores)
+
+    def _generate_with_callback(self, ids, mask, B, N, Lp, K, nret, max_length, length_penalty, fn, return_dict):
+        """Slow path for an ARBITRARY ``prefix_allowed_tokens_fn(batch_id, sent) -> List[int]`` (HF's
+        PrefixConstrainedLogitsProcessor contract): semantics preserved, one host round trip per step like the
+        reference (generation_trie.py:89-95).  The model still runs on the device through the same C-ABI entry
+        points (encode, decode step, LSE, beam step, finalize); only the allowed-token lists come from Python,
+        uploaded each step as a one-level CSR in which row r owns node r + 1."""
+        lib = _lib.load()
+        dev = self._device()
+        handle = self._pack()
+        ws = self._get_workspace(handle, B, N, Lp, K, max_length)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        R, V = B * K, self.config.vocab_size
+        i32 = dict(dtype=torch.int32, device=dev)
+        t = dict(tokens=torch.zeros(R, **i32), node=torch.zeros(R, **i32), beam_scores=torch.zeros(R, dtype=torch.float32, device=dev),
+                 seq=torch.zeros(R, max_length, **i32), anc=torch.zeros(max_length, R, **i32), done=torch.zeros(B, **i32),
+                 n_hyps=torch.zeros(B, **i32), hyp_score=torch.zeros(B, K + 1, dtype=torch.float64, device=dev),
+                 worst=torch.zeros(B, dtype=torch.float64, device=dev), hyp_len=torch.zeros(B, K + 1, **i32),
+                 hyp_tok=torch.zeros(B, K + 1, max_length, **i32), error=torch.zeros(4, **i32))
+        st = _lib.BeamState(B=B, K=K, Tmax=max_length, length_penalty=length_penalty, eos=1, pad=0,
+                            **{k: v.data_ptr() for k, v in t.items()})
+        logits = torch.empty(R, V, dtype=torch.float32, device=dev)
+        lse = torch.empty(R, dtype=torch.float32, device=dev)
+
+        def csr(lists):
+            off = [0, 0]
+            toks = []
+            for l in lists:
+                toks += sorted(set(int(x) for x in l))
+                off.append(len(toks))
+            fan = max((off[i + 1] - off[i] for i in range(1, len(off) - 1)), default=0)
+            if K * max(fan, 1) > 16384:
+                raise _lib.GramHipError("prefix_allowed_tokens_fn returned too many tokens for the on-chip candidate sort")
+            a = torch.tensor(off, **i32)
+            b = torch.tensor(toks or [0], **i32)
+            c = torch.full((max(len(toks), 1),), -1, **i32)
+            return _lib.Trie(a.data_ptr(), b.data_ptr(), c.data_ptr(), len(off) - 1, len(toks), max(fan, 1)), (a, b, c)
+
+        with torch.cuda.device(dev):
+            _lib.check(lib.gram_encode_fused(handle, ids.data_ptr(), mask.data_ptr(), B, N, Lp, ws.data_ptr(), ws.numel(), K,
+                                             max_length, None, stream), "gram_encode_fused")
+            start_trie, keep = csr([[0]])  # root -> start token, so that gram_beam_init finds node 1 for every row
+            start_trie.n_nodes = 2
+            _lib.check(lib.gram_beam_init(C.byref(st), C.byref(start_trie), 0, stream), "gram_beam_init")
+            for step in range(max_length - 1):
+                sent = t["seq"][:, : step + 1].cpu()
+                lists = [fn(r // K, sent[r]) for r in range(R)]  # the reference's per-beam callback
+                step_trie, keep = csr(lists)
+                t["node"].copy_(torch.arange(1, R + 1, **i32))
+                _lib.check(lib.gram_decode_step(handle, t["tokens"].data_ptr(), t["anc"].data_ptr(), mask.data_ptr(), B, N, Lp, K,
+                                                max_length, step, ws.data_ptr(), ws.numel(), logits.data_ptr(), stream),
+                           "gram_decode_step")
+                _lib.check(lib.gram_row_lse(logits.data_ptr(), lse.data_ptr(), R, V, stream), "gram_row_lse")
+                _lib.check(lib.gram_beam_step(C.byref(st), C.byref(step_trie), logits.data_ptr(), lse.data_ptr(), V, step + 1, K,
+                                              stream), "gram_beam_step")
+                torch.cuda.current_stream(dev).synchronize()  # the CSR tensors must outlive the launch
+            seqs = torch.empty(B * nret, max_length, dtype=torch.int64, device=dev)
+            scores = torch.empty(B * nret, dtype=torch.float32, device=dev)
+            width = torch.zeros(4, **i32)
+            _lib.check(lib.gram_beam_finalize(C.byref(st), nret, max_length, seqs.data_ptr(), scores.data_ptr(), width.data_ptr(),
+                                              stream), "gram_beam_finalize")
+            torch.cuda.current_stream(dev).synchronize()
+        if int(t["error"][0]) != 0:
+            _lib.check(_lib.E_BEAM, "beam search")
+        seqs = seqs[:, : int(width[0])]
+        return GenerateOutput(sequences=seqs, sequences_scores=scores) if return_dict else seqs
 
     def __del__(self):
         try:

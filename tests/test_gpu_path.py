@@ -313,3 +313,34 @@ def test_greedy_matches_oracle(gpu):
     assert same >= B - 2
     if same == B:
         assert dseq.shape == rseq.shape and torch.equal(dseq, rseq)
+
+
+def test_generic_callback_matches_trie_fast_path(gpu):
+    """An arbitrary prefix_allowed_tokens_fn (no Trie in its closure) goes through the step-wise fallback; with a
+    callback that answers from the same candidate set it must reproduce the fast path's sequences and scores."""
+    from gram_amd.utils import generation_trie as gt
+    oc, sd, m = _model(gpu, "tiny", 11)
+    g = torch.Generator().manual_seed(77)
+    B, N, L, K = 3, 2, 32, 5
+    ids, mask = _inputs(g, B, N, L, 256)
+    cands = _random_items(g, 60, 2, 4, 40)
+    max_length = max(len(c) for c in cands)
+    trie = gt.Trie(cands)
+    fast = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max_length,
+                      prefix_allowed_tokens_fn=gt.prefix_allowed_tokens_fn(trie), num_beams=K, num_return_sequences=K)
+    table = {}
+    for c in cands:
+        for i in range(1, len(c)):
+            table.setdefault(tuple(c[:i]), set()).add(c[i])
+    calls = []
+
+    def generic(batch_id, sent):  # plain function: nothing Trie-like in its closure cells
+        calls.append(batch_id)
+        return sorted(table.get(tuple(int(x) for x in sent), ()))
+
+    slow = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max_length, prefix_allowed_tokens_fn=generic,
+                      num_beams=K, num_return_sequences=K)
+    assert len(calls) == B * K * (max_length - 1) and set(calls) == set(range(B))
+    assert torch.equal(slow["sequences"].cpu(), fast["sequences"].cpu())
+    # dense logits + row LSE vs sparse logits + fused LSE partials: same values up to fp32 summation order
+    assert torch.allclose(slow["sequences_scores"].cpu(), fast["sequences_scores"].cpu(), atol=2e-5)
