@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--stagger", type=int, default=-1)
+    ap.add_argument("--fullcheck", action="store_true", help="compare every output row against torch (default: first 256)")
     ap.add_argument("--fuse", action="store_true", help="time the folded-layernorm epilogues (gram_norm_fusion_t)")
     a = ap.parse_args()
     lib = _lib.load()
@@ -52,6 +53,12 @@ def main():
                 continue
             torch.cuda.synchronize()
             err = (C[:256].float() - ref).abs().max().item()
+            if a.fullcheck:
+                for r0 in range(0, M, 8192):
+                    rr = A[r0:r0 + 8192].float() @ W.float().T
+                    if epi == _lib.EPI_BF16_RELU:
+                        rr = rr.clamp(min=0)
+                    err = max(err, (C[r0:r0 + 8192].float() - rr).abs().max().item())
             ok = err < (2e-3 if f32 else 3e-2)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             run = lambda: G.gemm(A, W, epi, C)
