@@ -25,6 +25,7 @@
 // XCD walks a contiguous range of tiles, n-tile fastest, so an A row-panel is fetched by one
 // XCD only and the (small) weight matrix stays L2-resident.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "prof.h"
@@ -34,7 +35,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
-enum { V_REG2 = 0, V_DMA = 1, V_DMA2 = 2, V_DMA_M256 = 3, V_DMA2_M256 = 4, V_DMA2_256SQ = 5, V_DMA_256SQ = 6, V_RING = 7, V_IL = 8, V_W4 = 13 };
+enum { V_REG2 = 0, V_DMA = 1, V_DMA2 = 2, V_DMA_M256 = 3, V_DMA2_M256 = 4, V_DMA2_256SQ = 5, V_DMA_256SQ = 6, V_RING = 7, V_IL = 8, V_W4 = 13, V_PP = 22 };
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
 int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain), see gemm_il_kernel
 
@@ -828,6 +829,9 @@ __device__ __forceinline__ void epilogue_rows_w4(f32x4 (&acc)[8][8], char* patch
 __device__ __forceinline__ void dma16_asm(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
 }
+__device__ __forceinline__ void dma4_asm(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int EPI, int ABL = 0>
@@ -1003,6 +1007,531 @@ int launch_w4(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// V_PP: persistent 256x256 "ping-pong" kernel.  8 waves = 2 groups (wr = wave >> 2) x 4 column slices
+// (wc = wave & 3); a wave owns 128 rows x 64 columns = 4 quadrants of 64 x 32.  A k-tile (BK = 64) is
+// computed in 4 phases, one quadrant each (16 MFMAs); a phase is a LOAD slot (ds_reads of the operand
+// sub-tiles the quadrant needs + this wave's share of one 16-KiB half-tile DMA) and an MFMA slot, each
+// ended by a workgroup barrier.  Group 1 runs ONE barrier behind group 0, so on every SIMD (which hosts
+// one wave of each group) the MFMA slot of one wave coincides with the load slot of the other: the
+// matrix pipe never waits for a DMA issue or an LDS read of its own wave.
+//
+// LDS: 8 half-tile buffers of 16 KiB = 2 (k-tile parity) x 4 types, in the order a k-tile consumes them:
+//   H0 = A rows of the m0 quadrants (rows wr*128 + 0..63),  H1 = W rows of the n0 quadrants (cols wc*64 + 0..31),
+//   H2 = W rows of the n1 quadrants (cols wc*64 + 32..63),  H3 = A rows of the m1 quadrants (rows wr*128 + 64..127).
+// Phase p of stream k-tile kk:   reads                      issues the DMA of
+//   p0  quadrant (m0,n0)         H0 (8 frags) + H1 (4)      (kk+1, H3)
+//   p1  quadrant (m0,n1)         H2 (4)                     (kk+2, H0)
+//   p2  quadrant (m1,n1)         H3 (8)                     (kk+2, H1)
+//   p3  quadrant (m1,n0)         --                         (kk+2, H2)
+// Every buffer is re-filled the phase after its only reading phase and needed again 6-7 phases later, so
+// the counted wait after each issue is s_waitcnt vmcnt(10): all but the 5 newest half-tiles (2 DMA
+// instructions per wave each) have landed, which is exactly what the NEXT phase reads.  The k-tiles of
+// all the tiles a workgroup walks form one stream, so the pipeline never drains between tiles.
+__device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// Store the wave's output rows of m-tiles j0, j0+1 (32 rows x 64 columns) through its LDS patch as whole
+// 128-B (bf16) / 256-B (fp32) row segments, 16 rows per pass.  Runs inside a LOAD slot of the ping-pong
+// kernel.  All global addresses are a wave-uniform base (this wave's first row / first column of the tile, so it
+// lives in SGPRs) + a 32-bit per-lane offset.  rows = number of valid rows from the wave's first row on.
+// rs: this wave group's 128 row scales in LDS (folded T5LayerNorm), or nullptr.
+struct PPOut {
+  char* c;          // C + (m_first * ldc + n_first) * esize
+  char* xb;         // xb_out likewise (bf16), or nullptr
+  float* ss;        // ss_out + m_first * nblk + n_first / 64, or nullptr
+  uint32_t ldc_b;   // ldc * esize
+  uint32_t ldx_b;   // ldc * 2
+  uint32_t ss_nblk;
+  int rows;
+};
+template <int EPI, bool FULL, int SMODE = 0>
+__device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, char* patch, const PPOut& o, int lane_, const float* rs) {
+  // opaque copy of the lane id: keeps hipcc from hoisting every store address of the tile out of the k-loop
+  // (loop-invariant, 2 VGPRs each) and spilling them -- a scratch reload inside a load slot is a vmcnt(0) drain
+  int lane = lane_;
+  asm volatile("" : "+v"(lane));
+  const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = j0 + jj;
+    if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
+      // 16 rows x 64 cols bf16: patch[16][128 B], chunk c (16 B) at c ^ (row & 7)
+      const float sc = rs ? rs[j * 16 + r16] : 1.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = acc[i][j] * sc;
+        if constexpr (EPI == GRAM_EPI_BF16_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        const int chunk = (i * 2 + (g >> 1)) ^ (r16 & 7);
+        *reinterpret_cast<uint2*>(patch + r16 * 128 + chunk * 16 + (g & 1) * 8) = pack_bf16x4(v);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const uint4 val = *reinterpret_cast<const uint4*>(patch + row * 128 + ((c ^ (row & 7)) * 16));
+        const int mr = j * 16 + row;
+        if constexpr (SMODE == 1) {
+          asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));
+        } else {
+          if (FULL || mr < o.rows) *reinterpret_cast<uint4*>(o.c + ((uint32_t)mr * o.ldc_b + c * 16)) = val;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      // 16 rows x 64 cols fp32: patch[16][256 B], chunk c (16 B) at c ^ row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int chunk = (i * 4 + g) ^ r16;
+        *reinterpret_cast<f32x4*>(patch + r16 * 256 + chunk * 16) = acc[i][j];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 4 + (lane >> 4), c = lane & 15;
+        f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16));
+        const int mr = j * 16 + row;
+        float ssq = 0.f;
+        if (FULL || mr < o.rows) {
+          f32x4* pc = reinterpret_cast<f32x4*>(o.c + ((uint32_t)mr * o.ldc_b + c * 16));
+          if constexpr (EPI == GRAM_EPI_F32_ADD) val += *pc;
+          *pc = val;
+          if constexpr (EPI == GRAM_EPI_F32_ADD) {
+            if (o.xb) {
+              *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + c * 8)) = pack_bf16x4(val);
+              ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
+            }
+          }
+        }
+        if constexpr (EPI == GRAM_EPI_F32_ADD) {
+          if (o.ss) {  // the 16 lanes of a row cover exactly one 64-column block
+            ssq += __shfl_xor(ssq, 1, 64);
+            ssq += __shfl_xor(ssq, 2, 64);
+            ssq += __shfl_xor(ssq, 4, 64);
+            ssq += __shfl_xor(ssq, 8, 64);
+            if (c == 0 && (FULL || mr < o.rows)) o.ss[(uint32_t)mr * o.ss_nblk] = ssq;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// full: all 128 rows of the wave exist (no per-row predicates: the stores of a pass issue back to back and
+// their number is exact, which the counted DMA waits of the following slots rely on)
+template <int EPI, int SMODE = 0>
+__device__ __forceinline__ void pp_store_rows(f32x4 (&acc)[4][8], int j0, char* patch, const PPOut& o, int lane, const float* rs) {
+  if (o.rows >= 128) pp_store_rows_impl<EPI, true, SMODE>(acc, j0, patch, o, lane, rs);
+  else pp_store_rows_impl<EPI, false, SMODE>(acc, j0, patch, o, lane, rs);
+}
+
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
+                                                         int K, int lda, EpiArgs ep, int ntiles, int stagger) {
+  constexpr int TB = 256, HT = 16384;
+  constexpr bool F32OUT = EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD;
+  // epilogue patches: fp32 outputs 8 x 4 KiB (one per wave, used in load slots); bf16 outputs 4 x 4 KiB, shared by
+  // waves w and w+4 -- the two groups use them in alternate time slots (each inside its own MFMA slot)
+  constexpr int PATCH = 4096;
+  constexpr int RS_OFF = 8 * HT + 4 * 4096;  // bf16 epilogues: 2 x 1 KiB of row scales behind the patches
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 8 half-tile buffers + epilogue patches (+ row scales)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell hipcc it is wave-uniform: everything derived stays in SGPRs
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ntn = N / TB;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3, q = G >> 3, rr = G & 7;
+  const int slot = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
+  if (slot >= ntiles) return;
+  const int nkt = K / BK;  // even, >= 4 (checked by the launcher)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);  // this wave's 2 pieces (16 rows) of a half-tile
+  const char* const Ab = reinterpret_cast<const char*>(A);
+  const char* const Wb = reinterpret_cast<const char*>(W);
+  char* const patch = smem + 8 * HT + (F32OUT ? wave : (wave & 3)) * PATCH;
+  const bool has_rs = !F32OUT && ep.ss_in != nullptr;  // ss_nblk == 0 (1/rms per row), checked by the launcher
+
+  // DMA cursor = stream k-tile kk+2 (tile, kt) + per-lane byte offsets of this wave's 2 pieces of each half-tile type
+  // (relative to the tile's first A row / W row, whose addresses c_A / c_W are wave-uniform and 64-bit)
+  int c_tile = slot, c_kt = 0;
+  // W offsets never change (H2 = H1 + 32 rows goes into the uniform base); A offsets change only for the M-tail tile
+  const char *c_A, *c_W;
+  uint32_t offA[2][2], offW[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = (wave * 2 + p) * 8 + (lane >> 3);  // row of the half-tile image
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    offW[p] = ((uint32_t)((r >> 5) * 64 + (r & 31)) * (uint32_t)K + chunk * 8) * 2u;
+  }
+  auto set_offsets = [&]() {
+    const int mt = c_tile / ntn, nt = c_tile - mt * ntn;
+    c_A = Ab + (size_t)mt * TB * lda * 2;
+    c_W = Wb + (size_t)nt * TB * K * 2;
+    const int mleft = M - 1 - mt * TB;  // last valid row, tile-relative
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // opaque: recompute the lane constants here (once per tile) instead of keeping them live
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = (wave * 2 + p) * 8 + (ln >> 3);
+      const int chunk = (ln & 7) ^ ((r >> 1) & 7);
+      const int arow = (r >> 6) * 128 + (r & 63);  // + 64 for H3
+      offA[0][p] = ((uint32_t)min(arow, mleft) * (uint32_t)lda + chunk * 8) * 2u;
+      offA[1][p] = ((uint32_t)min(arow + 64, mleft) * (uint32_t)lda + chunk * 8) * 2u;
+    }
+  };
+  auto advance = [&]() {
+    if (++c_kt == nkt) {
+      c_kt = 0;
+      if (c_tile + G < ntiles) c_tile += G;  // past the end of the stream: fetch this tile again (harmless, keeps the counts uniform)
+      set_offsets();
+    }
+  };
+  auto issue = [&](int t, int par) {  // this wave's 2 DMA instructions of half-tile (cursor, type t) -> buffer (par, t)
+    if constexpr (ABL != 2) {
+      const uint32_t dst = wave_lds + (par * 4 + t) * HT;
+      if (t == 0 || t == 3) {
+        const char* base = c_A + c_kt * (BK * 2);
+        dma16_asm(dst, offA[t == 3][0], base);
+        dma16_asm(dst + 1024, offA[t == 3][1], base);
+      } else {
+        const char* base = c_W + c_kt * (BK * 2) + (t == 2 ? (size_t)32 * K * 2 : 0);
+        dma16_asm(dst, offW[0], base);
+        dma16_asm(dst + 1024, offW[1], base);
+      }
+    }
+  };
+
+  f32x4 acc[4][8];
+  bf16x8 fa[2][4], fw[2][2][2];
+  // fragment addresses: one per-lane base per operand and k-step; the m-/n-tile (16 rows = 2 KiB: the swizzle term
+  // (row >> 1) & 7 does not change) and the buffer are immediate offsets
+  const char* const a_base[2] = {smem + swz(wr * 64 + r16, g), smem + swz(wr * 64 + r16, 4 + g)};
+  const char* const w_base[2] = {smem + swz(wc * 32 + r16, g), smem + swz(wc * 32 + r16, 4 + g)};
+  auto read_a = [&](int par, int mq) {
+    if constexpr (ABL != 5) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          fa[ks][j] = *reinterpret_cast<const bf16x8*>(a_base[ks] + (par * 4 + (mq ? 3 : 0)) * HT + j * 2048);
+    }
+  };
+  auto read_w = [&](int par, int nq) {
+    if constexpr (ABL != 5) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          fw[nq][ks][i] = *reinterpret_cast<const bf16x8*>(w_base[ks] + (par * 4 + 1 + nq) * HT + i * 2048);
+    }
+  };
+  auto mma = [&](int mq, int nq) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (ABL != 1) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[nq * 2 + i][mq * 4 + j] = mfma16(fw[nq][ks][i], fa[ks][j], acc[nq * 2 + i][mq * 4 + j]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    pp_barrier();
+  };
+  constexpr bool STORES = ABL != 3 && ABL != 5;
+  // bf16 epilogues: an MFMA slot that also stores the 32 finished rows of m-tiles J0, J0+1 (not the quadrant being
+  // computed).  Scale/convert/ds_write pieces fill the issue gaps of the first 8 MFMAs, the patch reads those of
+  // the next 4, and the 4 row-contiguous global stores go out behind the last MFMA, so the slot is barely longer.
+  auto mma_st = [&](int mq, int nq, auto J0c, const PPOut& o, const float* rs) {
+    constexpr int J0 = decltype(J0c)::value;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // opaque: no hoisting of the addresses below out of the k-loop (they would be spilled)
+    const int lr = ln & 15, lg = ln >> 4;
+    float sc[2] = {1.f, 1.f};
+    if (rs) {
+      sc[0] = rs[J0 * 16 + lr];
+      sc[1] = rs[J0 * 16 + 16 + lr];
+    }
+    uint4 pva;
+    // register-lean addressing: one per-lane base each for the patch writes, the patch reads and the stores
+    //   write (m-tile jj, n-tile pi): row = jj*16 + lr, 16-B chunk (pi*2 + (lg>>1)) ^ (lr & 7), half lg & 1
+    //     = wbase + jj*2048 + ((pi*32) ^ wx)   with wbase, wx per lane
+    const int wx = ((lr & 7) >> 1) * 32;
+    const char* const wbase = patch + lr * 128 + (((lg >> 1) ^ (lr & 1)) * 16) + (lg & 1) * 8;
+    //   read it: row = it*8 + (ln>>3), chunk (ln & 7) ^ (row & 7)  = gbase + it*1024
+    const char* const gbase = patch + (ln >> 3) * 128 + (((ln & 7) ^ ((ln >> 3) & 7)) * 16);
+    //   store it: row J0*16 + it*8 + (ln>>3), 16 B at column (ln & 7)*8
+    const int mr0 = J0 * 16 + (ln >> 3);
+    const uint32_t voff0 = (uint32_t)mr0 * o.ldc_b + (ln & 7) * 16;
+    auto get = [&](int it) { return *reinterpret_cast<const uint4*>(gbase + it * 1024); };
+    auto put = [&](int it, const uint4& v) {  // -> its 128-B segment of C
+      if constexpr (ABL == 6) {
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+      } else {
+        if (mr0 + it * 8 < o.rows) {
+          uint4* dst = reinterpret_cast<uint4*>(o.c + (voff0 + (uint32_t)(it * 8) * o.ldc_b));
+          // streaming (nt) store: the output is far larger than L2 and is next read by another kernel; keeping it
+          // out of L2 leaves the A panels this XCD re-reads there (measured +1.6 ... 4 %)
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          if constexpr (ABL == 7) *dst = v;  // ablation: default cache policy
+          else __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst));
+        }
+      }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      const int ks = n >> 3, i = (n >> 2) & 1, j = n & 3;
+      if constexpr (ABL != 1) acc[nq * 2 + i][mq * 4 + j] = mfma16(fw[nq][ks][i], fa[ks][j], acc[nq * 2 + i][mq * 4 + j]);
+      if (n < 8 && (n & 1)) {
+#pragma unroll
+        for (int pc = n - 1; pc <= n; ++pc) {  // piece pc: m-tile J0 + (pc >> 2), n-tile pc & 3
+          const int jj = pc >> 2, pi = pc & 3;
+          f32x4 v = acc[pi][J0 + jj] * sc[jj];
+          if constexpr (EPI == GRAM_EPI_BF16_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *reinterpret_cast<uint2*>(const_cast<char*>(wbase) + jj * 2048 + ((pi * 32) ^ wx)) = pack_bf16x4(v);
+        }
+      }
+      if (n == 7) __builtin_amdgcn_wave_barrier();
+      if (n == 8) pva = get(0);
+      if (n == 10) {
+        put(0, pva);
+        pva = get(1);
+      }
+      if (n == 12) {
+        put(1, pva);
+        pva = get(2);
+      }
+      if (n == 14) {
+        put(2, pva);
+        pva = get(3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    put(3, pva);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the shared patch is idle before the other group's slot
+    __builtin_amdgcn_sched_barrier(0);
+    pp_barrier();
+  };
+  // extra = number of epilogue stores this wave has issued since the DMA that must have landed (a lower bound is
+  // always safe: vmcnt counts loads, stores and DMA together, in issue order)
+  auto end_load_slot = [&](int extra = 0) {
+    // all but this wave's 6 newest half-tiles (2 DMA each) have landed
+    if (extra == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (extra == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (extra == 8) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (extra == 12) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this slot's LDS reads are complete before their buffer can be re-filled
+    __builtin_amdgcn_sched_barrier(0);
+    pp_barrier();
+  };
+  auto zero_half = [&](int mq) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][mq * 4 + j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
+  // Consumption order of the half-tile stream (one per phase; nf = parity of the k-tile, ns = 1 - nf):
+  //   ... W_nf(kk) [read in the previous k-tile's p3] | A_m0(kk) p0 | W_ns(kk) p1 | A_m1(kk) p2 | W_nf(kk+1) p3 | ...
+  // Phase P issues the half-tile consumed in phase P + 7 (all of stream k-tile kk+2) into the buffer whose only
+  // reading phase was P - 1, and then waits for all but its 6 newest half-tiles.
+  if (stagger > 0) {  // de-synchronise the CUs' store phases
+    const int units = ((slot & 7) * stagger * nkt) >> 3;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);  // 512 cycles
+  }
+  // ---- prologue: everything phases -8 .. -1 would have issued = all of stream k-tiles 0 and 1
+  set_offsets();
+  issue(1, 0);
+  issue(0, 0);
+  issue(2, 0);
+  issue(3, 0);
+  advance();
+  issue(2, 1);
+  issue(0, 1);
+  issue(1, 1);
+  issue(3, 1);
+  advance();
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // W_n0(0) and A_m0(0) have landed
+  pp_barrier();
+  read_w(0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (wr == 1) pp_barrier();  // group 1 runs one barrier behind group 0
+
+  int tile = slot;
+  int m0, n0, tpar = 0;
+  constexpr int ESZ = F32OUT ? 4 : 2;
+  int pm0 = 0, pn0 = 0;
+  // output addressing of tile (tm0, tn0), built where it is used (a handful of SALU ops) rather than kept live
+  auto make_out = [&](int tm0, int tn0) {  // this wave's first row (tm0 + wr*128) and first column (tn0 + wc*64)
+    PPOut o;
+    const size_t mf = (size_t)tm0 + wr * 128;
+    const int nf = tn0 + wc * 64;
+    o.c = reinterpret_cast<char*>(ep.C) + (mf * ep.ldc + nf) * ESZ;
+    o.xb = ep.xb_out ? reinterpret_cast<char*>(ep.xb_out) + (mf * ep.ldc + nf) * 2 : nullptr;
+    o.ss = ep.ss_out ? ep.ss_out + mf * ep.ss_out_nblk + (nf >> 6) : nullptr;
+    o.ldc_b = ep.ldc * ESZ;
+    o.ldx_b = ep.ldc * 2;
+    o.ss_nblk = ep.ss_out_nblk;
+    o.rows = M - (int)mf;
+    return o;
+  };
+  bool pending = false;  // the m1 half of the previous tile is still in the accumulators
+  zero_half(0);
+  zero_half(1);
+  while (true) {
+    {
+      const int mt = tile / ntn, nt = tile - mt * ntn;
+      m0 = mt * TB;
+      n0 = nt * TB;
+    }
+    const float* rs_cur = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + tpar * 256 + wr * 128 : nullptr;
+    const float* rs_prev = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128 : nullptr;
+    for (int kt = 0; kt < nkt; kt += 2) {
+      const bool first = kt == 0, last = kt + 2 >= nkt;
+      // bf16 epilogues of FULL tiles issue exactly 4 stores per store slot (the slots p2, p3 of a tile's last k-tile
+      // and p0, p1 of the next tile's first): pf / lf = such stores were / are issued around this k-tile pair
+      const bool pf = !F32OUT && STORES && first && pending && M - (pm0 + wr * 128) >= 128;
+      const bool lf = !F32OUT && STORES && last && M - (m0 + wr * 128) >= 128;
+      // ================= even k-tile (buffers 0): n order 0, 1
+      // Epilogue of the previous tile's m1 half (m-tiles 4..7, finished by its last MFMA slot): fp32 outputs store it
+      // in the load slots of p0 / p1, bf16 outputs inside the MFMA slots of p0 / p1 (which compute m0 quadrants).
+      const bool st_prev = STORES && first && pending, st_cur = STORES && last;
+      read_a(0, 0);
+      if constexpr (F32OUT) {
+        if (st_prev) pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, patch, make_out(pm0, pn0), lane, nullptr);
+      }
+      issue(1, 0);  // W_n0(kk+2)
+      end_load_slot(pf ? 8 : 0);
+      if (!F32OUT && st_prev) mma_st(0, 0, std::integral_constant<int, 4>{}, make_out(pm0, pn0), rs_prev);
+      else mma(0, 0);
+      read_w(0, 1);
+      if constexpr (F32OUT) {
+        if (st_prev) pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, patch, make_out(pm0, pn0), lane, nullptr);
+      }
+      issue(0, 0);  // A_m0(kk+2)
+      end_load_slot(pf ? 12 : 0);
+      if (!F32OUT && st_prev) mma_st(0, 1, std::integral_constant<int, 6>{}, make_out(pm0, pn0), rs_prev);
+      else mma(0, 1);
+      read_a(0, 1);
+      if (first) {
+        zero_half(1);
+        if (has_rs && wave < 4) {  // this tile's 256 row scales -> LDS by DMA (64 rows per wave); first read >= 6 k-tiles later
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          dma4_asm(lds0 + RS_OFF + tpar * 1024 + wave * 256, (uint32_t)min(m0 + wave * 64 + ln, M - 1) * 4u,
+                   reinterpret_cast<const char*>(ep.ss_in));
+        }
+      }
+      issue(2, 0);  // W_n1(kk+2)
+      end_load_slot(pf ? 16 : 0);
+      mma(1, 1);
+      read_w(1, 1);  // W_n1 of the odd k-tile that follows
+      issue(3, 0);   // A_m1(kk+2)
+      end_load_slot(pf ? 16 : 0);
+      mma(1, 0);
+      advance();
+      // ================= odd k-tile (buffers 1): n order 1, 0
+      read_a(1, 0);
+      issue(2, 1);  // W_n1(kk+3)
+      end_load_slot(pf ? 16 : 0);
+      mma(0, 1);
+      read_w(1, 0);
+      issue(0, 1);  // A_m0(kk+3)
+      end_load_slot(pf ? 12 : 0);
+      mma(0, 0);
+      // this tile's m0 half (m-tiles 0..3) is final now: stored during p2 / p3, which compute the m1 quadrants
+      read_a(1, 1);
+      if constexpr (F32OUT) {
+        if (st_cur) pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 0, patch, make_out(m0, n0), lane, nullptr);
+      }
+      issue(1, 1);  // W_n0(kk+3)
+      end_load_slot(pf ? 8 : 0);
+      if (!F32OUT && st_cur) mma_st(1, 0, std::integral_constant<int, 0>{}, make_out(m0, n0), rs_cur);
+      else mma(1, 0);
+      read_w(0, 0);  // W_n0 of the even k-tile that follows
+      if constexpr (F32OUT) {
+        if (st_cur) pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 2, patch, make_out(m0, n0), lane, nullptr);
+      }
+      issue(3, 1);  // A_m1(kk+3)
+      end_load_slot((pf ? 4 : 0) + (lf ? 4 : 0));
+      if (!F32OUT && st_cur) mma_st(1, 1, std::integral_constant<int, 2>{}, make_out(m0, n0), rs_cur);
+      else mma(1, 1);
+      if (last) zero_half(0);
+      advance();
+    }
+    pending = true;
+    pm0 = m0;
+    pn0 = n0;
+    tpar ^= 1;
+    if (tile + G >= ntiles) break;
+    tile += G;
+  }
+  // The last tile's m1 half is still in the accumulators.  Every DMA of this workgroup must have landed before it
+  // ends, and after that the half-tile buffers are dead: they serve as 8 private patches for the final stores.
+  if (wr == 0) pp_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  pp_barrier();
+  if constexpr (!STORES) {
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (keep == 123.456f) reinterpret_cast<float*>(ep.C)[0] = keep;
+  } else {
+    const float* rs_prev = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128 : nullptr;
+    const PPOut o = make_out(pm0, pn0);
+    pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, smem + wave * 4096, o, lane, rs_prev);
+    pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, smem + wave * 4096, o, lane, rs_prev);
+  }
+}
+
+template <int EPI, int ABL = 0>
+int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+  constexpr int smem = 8 * 16384 + 8 * 4096;  // 160 KiB
+  if (N % 256 || (K / BK) % 2 || K / BK < 4 || (ep.ss_in && ep.ss_nblk != 0)) return GRAM_E_ARG;
+  if ((size_t)256 * lda * 2 >= (1ull << 31) || (size_t)256 * K * 2 >= (1ull << 31) || (size_t)256 * ep.ldc * 4 >= (1ull << 31))
+    return GRAM_E_ARG;  // per-tile 32-bit offsets
+  if constexpr (EPI == GRAM_EPI_KV_BANK || EPI == GRAM_EPI_F32_LSE) {
+    return GRAM_E_ARG;
+  } else {
+    const int ntiles = (N / 256) * ((M + 255) / 256);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GRAM_E_ARG;
+      n_cu = prop.multiProcessorCount;
+    }
+    const int nblocks = ntiles < n_cu ? ntiles : n_cu;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<EPI, ABL>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda,
+                       ep, ntiles, g_stagger);
+    GRAM_CHECK_LAUNCH();
+    return 0;
+  }
+}
+
 // Measured on MI355X (tests/bench_gemm.py, B = 512 shapes; TFLOP/s):
 //   M >= 32768 (encoder, bank):  V_IL (persistent 256x256, row-contiguous epilogue) 935-948 (521 for the
 //                                HBM-bound N=768,K=768 residual GEMM) > V_DMA_M256 780-815 > V_DMA
@@ -1053,7 +1582,17 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
     case V_DMA2_256SQ: return launch_dma<EPI, 4, 2, 8>(A, W, M, N, K, lda, ep, st);
     case V_DMA_256SQ: return launch_dma<EPI, 4, 1, 8>(A, W, M, N, K, lda, ep, st);
     case V_RING: return launch_ring<EPI>(A, W, M, N, K, lda, ep, st);
-    case V_IL: return launch_il<EPI>(A, W, M, N, K, lda, ep, st);
+    case V_IL: {
+      // the ping-pong kernel is faster for bf16 outputs (+12 %) and for long-K fp32 residual GEMMs (+5 %); it
+      // declines shapes it does not cover (GRAM_E_ARG) and those run on the plain persistent kernel
+      static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
+      if (use_pp && g_force_variant < 0 &&
+          (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || (EPI == GRAM_EPI_F32_ADD && K >= 2048 && use_pp >= 2))) {
+        const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
+        if (r != GRAM_E_ARG) return r;
+      }
+      return launch_il<EPI>(A, W, M, N, K, lda, ep, st);
+    }
     case 9: return launch_il<EPI, 1>(A, W, M, N, K, lda, ep, st);
     case 10: return launch_il<EPI, 2>(A, W, M, N, K, lda, ep, st);
     case 11: return launch_il<EPI, 3>(A, W, M, N, K, lda, ep, st);
@@ -1067,6 +1606,12 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
     case 19: return launch_w4<EPI, 7>(A, W, M, N, K, lda, ep, st);
     case 20: return launch_w4<EPI, 8>(A, W, M, N, K, lda, ep, st);
     case 21: return launch_w4<EPI, 9>(A, W, M, N, K, lda, ep, st);
+    case V_PP: return launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
+    case 23: return launch_pp<EPI, 3>(A, W, M, N, K, lda, ep, st);
+    case 24: return launch_pp<EPI, 2>(A, W, M, N, K, lda, ep, st);
+    case 25: return launch_pp<EPI, 5>(A, W, M, N, K, lda, ep, st);
+    case 26: return launch_pp<EPI, 6>(A, W, M, N, K, lda, ep, st);
+    case 27: return launch_pp<EPI, 7>(A, W, M, N, K, lda, ep, st);
     default: break;
   }
   const int nblocks = (N / BN) * ((M + BM - 1) / BM);

@@ -1,7 +1,11 @@
 #!/bin/bash
-# microbench: 8-wave persistent (8) vs 4-wave 128x128-wave-tile persistent (13) + ablations
+# microbench of the persistent GEMM variants (+ ablations) on the encoder shapes
+#   ab_w4.sh [batch] [variants] [shapes separated by ';']
 set -e
 B=${1:-512}
-for s in "enc qkv" "enc o" "enc wi" "enc wo"; do
-  timeout -k 10 120 python tests/bench_gemm.py --batch $B --variants ${2:-8,13,15,16,10,11} --only "$s" --fullcheck
+V=${2:-8,22,23}
+SH=${3:-"enc qkv;enc o;enc wi;enc wo"}
+IFS=';' read -ra SHAPES <<< "$SH"
+for s in "${SHAPES[@]}"; do
+  ${DRY:+echo} timeout -k 10 120 python tests/bench_gemm.py --batch "$B" --variants "$V" --only "$s" --fullcheck
 done

@@ -48,6 +48,58 @@ def test_gemm_epilogues(G, M, N, K):
     assert torch.allclose(acc, base + ref, atol=1e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (256 * 40 + 100, 2304, 768), (256 * 86, 768, 3072)])
+def test_gemm_persistent_variants(G, M, N, K):
+    """The two persistent 256x256 kernels (8 = DMA-interleaved, 22 = ping-pong 8-phase) on every epilogue they
+    implement: several tiles per workgroup (> 256 tiles), an M tail, and the folded-T5LayerNorm arguments
+    (consumer row scales staged through LDS, producer bf16 copy + sum-of-squares partials).  The k-order of the
+    fp32 accumulation is the same in both kernels, so their outputs are compared bit for bit."""
+    import ctypes as ct
+
+    from gram_amd import _lib
+    L_ = G.lib()
+    A, W = G.bf(_r(M, K, seed=11)), G.bf(_r(N, K, seed=12, scale=K ** -0.5))
+    ref = A.float() @ W.float().T
+    rs = (torch.rand(M, generator=torch.Generator().manual_seed(13)) + 0.5).to(G.DEV)
+    base = _r(M, N, seed=14).to(G.DEV)
+    outs = {}
+    try:
+        for v in (8, 22):
+            L_.gram_debug_set_gemm_variant(v)
+            o = {}
+            for epi in (_lib.EPI_BF16, _lib.EPI_BF16_RELU):
+                y = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+                G.gemm(A, W, epi, y)
+                o[("plain", epi)] = y
+                y2 = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+                cons = _lib.NormFusion(None, None, rs.data_ptr(), 0, K, 1e-6)  # nblk_in = 0: ss_in holds 1/rms per row
+                _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(y2), M, N, K, K, N, epi, None, ct.byref(cons), G.stream()), "consumer")
+                o[("scaled", epi)] = y2
+            f = torch.zeros(M, N, dtype=torch.float32, device=G.DEV)
+            G.gemm(A, W, _lib.EPI_F32, f)
+            o["f32"] = f
+            x = base.clone()
+            xb = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+            ss = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=G.DEV)
+            prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
+            _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(x), M, N, K, K, N, _lib.EPI_F32_ADD, None, ct.byref(prod), G.stream()), "producer")
+            o["add"], o["xb"], o["ss"] = x, xb, ss
+            torch.cuda.synchronize()
+            outs[v] = o
+    finally:
+        L_.gram_debug_set_gemm_variant(-1)
+    for v, o in outs.items():
+        for epi, act in ((_lib.EPI_BF16, lambda t: t), (_lib.EPI_BF16_RELU, lambda t: t.clamp(min=0))):
+            assert torch.allclose(o[("plain", epi)].float(), act(ref), atol=2e-2, rtol=1e-2), (v, epi)
+            assert torch.allclose(o[("scaled", epi)].float(), act(ref * rs[:, None]), atol=3e-2, rtol=1e-2), (v, epi)
+        assert torch.allclose(o["f32"], ref, atol=1e-3, rtol=1e-4), v
+        assert torch.allclose(o["add"], base + ref, atol=2e-3, rtol=1e-4), v
+        assert torch.equal(o["xb"], o["add"].to(torch.bfloat16)), v
+        assert torch.allclose(o["ss"].sum(-1), (o["add"] * o["add"]).sum(-1), rtol=1e-5), v
+    for key in outs[8]:
+        assert torch.equal(outs[8][key], outs[22][key]), key
+
+
 def test_gemm_asymmetric_identity(G):
     """A = I with an asymmetric W catches a transposed / row-col swapped fragment mapping."""
     from gram_amd import _lib
