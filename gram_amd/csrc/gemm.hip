@@ -59,7 +59,23 @@ struct EpiArgs {
   int S, H, B, inner;
   const int32_t* pmap;  // compacted encoder rows: passage p = m / pL is flat passage pmap[p] = b*pN + n (NULL: identity)
   int pL, pN;
+  int nt;  // streaming (nt) stores in the persistent kernel's row-contiguous epilogue (A/B hook GRAM_GEMM_NT)
 };
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store16(void* p, uint4 v, bool nt) {
+  if (nt) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), reinterpret_cast<u32x4_t*>(p));
+  else *reinterpret_cast<uint4*>(p) = v;
+}
+__device__ __forceinline__ void store16(void* p, f32x4 v, bool nt) {
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+__device__ __forceinline__ void store8(void* p, uint2 v, bool nt) {
+  if (nt) __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, v), reinterpret_cast<u32x2_t*>(p));
+  else *reinterpret_cast<uint2*>(p) = v;
+}
 
 // XCD-aware bijective remap of the 1-D workgroup id -> (m-tile, n-tile), n fastest.
 __device__ __forceinline__ void tile_of_block(int ntn, int& mt, int& nt) {
@@ -539,7 +555,7 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[8][4], char* patch /*
         const int row = it * 4 + (lane >> 4), c = lane & 15;
         const uint4 val = *reinterpret_cast<const uint4*>(patch + row * 256 + ((c ^ (row & 15)) * 16));
         const int m = m0 + wm * 64 + pass * 32 + row;
-        if (m < M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 8) = val;
+        if (m < M) store16(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 8, val, ep.nt);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -562,10 +578,10 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[8][4], char* patch /*
         if (m < M) {
           f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4);
           if constexpr (EPI == GRAM_EPI_F32_ADD) val += *pc;
-          *pc = val;
+          store16(pc, val, ep.nt);
           if constexpr (EPI == GRAM_EPI_F32_ADD) {
             if (ep.xb_out) {
-              *reinterpret_cast<uint2*>(ep.xb_out + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4) = pack_bf16x4(val);
+              store8(ep.xb_out + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4, pack_bf16x4(val), ep.nt);
               ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
             }
           }
@@ -730,6 +746,8 @@ int launch_il(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  static const int nt_env = getenv("GRAM_GEMM_NT") ? atoi(getenv("GRAM_GEMM_NT")) : 0;
+  ep.nt = nt_env;
   hipLaunchKernelGGL((gemm_il_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep,
                      ntiles, g_stagger);
   GRAM_CHECK_LAUNCH();
@@ -1230,16 +1248,20 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
           fw[nq][ks][i] = *reinterpret_cast<const bf16x8*>(w_base[ks] + (par * 4 + 1 + nq) * HT + i * 2048);
     }
   };
-  auto mma = [&](int mq, int nq) {
+  // TR (KV bank, V^T half): operands the other way round, so a lane ends up with 4 consecutive ROWS (bank
+  // positions s) of one column d -- the V^T layout -- instead of 4 consecutive columns of one row
+  auto mfma_q = [&](auto TRc, int mq, int nq, int n) {
+    const int ks = n >> 3, i = (n >> 2) & 1, j = n & 3;
+    f32x4& c = acc[nq * 2 + i][mq * 4 + j];
+    if constexpr (decltype(TRc)::value) c = mfma16(fa[ks][j], fw[nq][ks][i], c);
+    else c = mfma16(fw[nq][ks][i], fa[ks][j], c);
+  };
+  auto mma = [&](int mq, int nq, auto TRc) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     if constexpr (ABL != 1) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[nq * 2 + i][mq * 4 + j] = mfma16(fw[nq][ks][i], fa[ks][j], acc[nq * 2 + i][mq * 4 + j]);
+      for (int n = 0; n < 16; ++n) mfma_q(TRc, mq, nq, n);
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -1249,7 +1271,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // bf16 epilogues: an MFMA slot that also stores the 32 finished rows of m-tiles J0, J0+1 (not the quadrant being
   // computed).  Scale/convert/ds_write pieces fill the issue gaps of the first 8 MFMAs, the patch reads those of
   // the next 4, and the 4 row-contiguous global stores go out behind the last MFMA, so the slot is barely longer.
-  auto mma_st = [&](int mq, int nq, auto J0c, const PPOut& o, const float* rs) {
+  auto mma_st = [&](int mq, int nq, auto TRc, auto J0c, const PPOut& o, const float* rs) {
     constexpr int J0 = decltype(J0c)::value;
     int ln = lane;
     asm volatile("" : "+v"(ln));  // opaque: no hoisting of the addresses below out of the k-loop (they would be spilled)
@@ -1289,8 +1311,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
-      const int ks = n >> 3, i = (n >> 2) & 1, j = n & 3;
-      if constexpr (ABL != 1) acc[nq * 2 + i][mq * 4 + j] = mfma16(fw[nq][ks][i], fa[ks][j], acc[nq * 2 + i][mq * 4 + j]);
+      if constexpr (ABL != 1) mfma_q(TRc, mq, nq, n);
       if (n < 8 && (n & 1)) {
 #pragma unroll
         for (int pc = n - 1; pc <= n; ++pc) {  // piece pc: m-tile J0 + (pc >> 2), n-tile pc & 3
@@ -1325,6 +1346,74 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     __builtin_amdgcn_sched_barrier(0);
     pp_barrier();
   };
+  // ---- KV bank (gram_kv_bank_t): where the 32-row block of m-tiles J0, J0+1 of tile (tm0, tn0) goes.  A wave's 64
+  // columns are one head of one layer's K or V projection; a 32-row block lies inside one passage (32 | L), so its
+  // user b and first bank position s0 are wave-uniform.
+  struct KVLoc {
+    char* kb;  // bank_k + ((head * S + s0) * 64): the block's 32 x 128 B of K
+    char* vb;  // bank_vt + (head * 64 * S + s0): column 0 of the block in V^T
+    int mblk;  // first row of the block in A
+  };
+  auto kv_locate = [&](int tm0, int tn0, int J0) {
+    KVLoc q;
+    q.mblk = tm0 + wr * 128 + J0 * 16;
+    int b_, s0;
+    if (ep.pmap) {
+      const int pp = q.mblk / ep.pL, l = q.mblk - pp * ep.pL, flat = ep.pmap[pp];
+      b_ = flat / ep.pN;
+      s0 = (flat - b_ * ep.pN) * ep.pL + l;
+    } else {
+      b_ = q.mblk / ep.S;
+      s0 = q.mblk - b_ * ep.S;
+    }
+    const int n = tn0 + wc * 64, lw = n / ep.inner;
+    const size_t head = ((size_t)(lw >> 1) * ep.B + b_) * ep.H + ((n - lw * ep.inner) >> 6);
+    q.kb = reinterpret_cast<char*>(ep.bank_k + (head * ep.S + s0) * 64);
+    q.vb = reinterpret_cast<char*>(ep.bank_vt + head * 64 * ep.S + s0);
+    return q;
+  };
+  auto kv_is_vt = [&](int tn0) { return (int)((tn0 / ep.inner) & 1); };
+  // one (m-tile jj, n-tile pi) fragment of the block straight from registers (8 B per lane)
+  // (wave-uniform base + 32-bit per-lane offset)
+  auto kv_direct = [&](auto TRc, const KVLoc& q, int jj, int pi, const f32x4& v, int lr, int lg) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 pk = __builtin_bit_cast(u32x2, pack_bf16x4(v));
+    if constexpr (decltype(TRc)::value) {  // lane: column d = pi*16 + lr, rows s0 + jj*16 + 4*lg .. +3
+      const uint32_t off = ((uint32_t)(pi * 16 + lr) * (uint32_t)ep.S + jj * 16 + 4 * lg) * 2u;
+      if (q.mblk + jj * 16 + 4 * lg < M) __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(q.vb + off));
+    } else {  // lane: row s0 + jj*16 + lr, columns d = pi*16 + 4*lg .. +3
+      const uint32_t off = ((uint32_t)(jj * 16 + lr) * 64u + pi * 16 + 4 * lg) * 2u;
+      if (q.mblk + jj * 16 + lr < M) __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(q.kb + off));
+    }
+  };
+  // MFMA slot + the V^T block of m-tiles J0, J0+1 (computed with swapped operands): 8 direct 8-B stores per lane,
+  // 16 d-rows x 32 B each (2-byte scatter in the plain kernel), issued in the gaps of the first 8 MFMAs
+  auto mma_vt = [&](int mq, int nq, auto TRc, auto J0c, const KVLoc& q) {
+    constexpr int J0 = decltype(J0c)::value;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int lr = ln & 15, lg = ln >> 4;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      if constexpr (ABL != 1) mfma_q(TRc, mq, nq, n);
+      if (n < 8) kv_direct(std::true_type{}, q, n >> 2, n & 3, acc[n & 3][J0 + (n >> 2)], lr, lg);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    pp_barrier();
+  };
+  // K half through the shared patch (whole 128-B rows): the block is 32 x 128 B contiguous in the bank
+  auto kv_out_k = [&](const KVLoc& q, int tm0, int J0) {
+    PPOut o{};
+    o.c = q.kb - (size_t)J0 * 16 * 128;
+    o.ldc_b = 128;
+    o.rows = M - (tm0 + wr * 128);
+    return o;
+  };
+  bool tr_cur = false;  // KV bank: the tile being computed is a V^T tile
   // extra = number of epilogue stores this wave has issued since the DMA that must have landed (a lower bound is
   // always safe: vmcnt counts loads, stores and DMA together, in issue order)
   auto end_load_slot = [&](int extra = 0) {
@@ -1389,6 +1478,33 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     o.rows = M - (int)mf;
     return o;
   };
+  // one MFMA slot of quadrant (mq, nq), optionally with the epilogue job "store m-tiles J0, J0+1 of tile (tm0, tn0)"
+  auto run_slot = [&](int mq, int nq, bool job, auto J0c, int tm0, int tn0, const float* rs) {
+    constexpr int J0 = decltype(J0c)::value;
+    if constexpr (EPI == GRAM_EPI_KV_BANK) {
+      KVLoc q{};
+      bool vt = false;
+      if (job) {
+        job = tm0 + wr * 128 + J0 * 16 < M;  // (a block past the M tail: nothing to store, and no pmap entry)
+        if (job) {
+          q = kv_locate(tm0, tn0, J0);
+          vt = kv_is_vt(tn0);
+        }
+      }
+      if (tr_cur) {
+        if (!job) mma(mq, nq, std::true_type{});
+        else if (vt) mma_vt(mq, nq, std::true_type{}, J0c, q);
+        else mma_st(mq, nq, std::true_type{}, J0c, kv_out_k(q, tm0, J0), nullptr);
+      } else {
+        if (!job) mma(mq, nq, std::false_type{});
+        else if (vt) mma_vt(mq, nq, std::false_type{}, J0c, q);
+        else mma_st(mq, nq, std::false_type{}, J0c, kv_out_k(q, tm0, J0), nullptr);
+      }
+    } else {
+      if (job) mma_st(mq, nq, std::false_type{}, J0c, make_out(tm0, tn0), rs);
+      else mma(mq, nq, std::false_type{});
+    }
+  };
   bool pending = false;  // the m1 half of the previous tile is still in the accumulators
   zero_half(0);
   zero_half(1);
@@ -1398,14 +1514,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       m0 = mt * TB;
       n0 = nt * TB;
     }
+    if constexpr (EPI == GRAM_EPI_KV_BANK) tr_cur = kv_is_vt(n0);
     const float* rs_cur = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + tpar * 256 + wr * 128 : nullptr;
     const float* rs_prev = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128 : nullptr;
     for (int kt = 0; kt < nkt; kt += 2) {
       const bool first = kt == 0, last = kt + 2 >= nkt;
       // bf16 epilogues of FULL tiles issue exactly 4 stores per store slot (the slots p2, p3 of a tile's last k-tile
       // and p0, p1 of the next tile's first): pf / lf = such stores were / are issued around this k-tile pair
-      const bool pf = !F32OUT && STORES && first && pending && M - (pm0 + wr * 128) >= 128;
-      const bool lf = !F32OUT && STORES && last && M - (m0 + wr * 128) >= 128;
+      const bool pf = !F32OUT && EPI != GRAM_EPI_KV_BANK && STORES && first && pending && M - (pm0 + wr * 128) >= 128;
+      const bool lf = !F32OUT && EPI != GRAM_EPI_KV_BANK && STORES && last && M - (m0 + wr * 128) >= 128;
       // ================= even k-tile (buffers 0): n order 0, 1
       // Epilogue of the previous tile's m1 half (m-tiles 4..7, finished by its last MFMA slot): fp32 outputs store it
       // in the load slots of p0 / p1, bf16 outputs inside the MFMA slots of p0 / p1 (which compute m0 quadrants).
@@ -1416,16 +1533,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       }
       issue(1, 0);  // W_n0(kk+2)
       end_load_slot(pf ? 8 : 0);
-      if (!F32OUT && st_prev) mma_st(0, 0, std::integral_constant<int, 4>{}, make_out(pm0, pn0), rs_prev);
-      else mma(0, 0);
+      run_slot(0, 0, !F32OUT && st_prev, std::integral_constant<int, 4>{}, pm0, pn0, rs_prev);
       read_w(0, 1);
       if constexpr (F32OUT) {
         if (st_prev) pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, patch, make_out(pm0, pn0), lane, nullptr);
       }
       issue(0, 0);  // A_m0(kk+2)
       end_load_slot(pf ? 12 : 0);
-      if (!F32OUT && st_prev) mma_st(0, 1, std::integral_constant<int, 6>{}, make_out(pm0, pn0), rs_prev);
-      else mma(0, 1);
+      run_slot(0, 1, !F32OUT && st_prev, std::integral_constant<int, 6>{}, pm0, pn0, rs_prev);
       read_a(0, 1);
       if (first) {
         zero_half(1);
@@ -1438,21 +1553,21 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       }
       issue(2, 0);  // W_n1(kk+2)
       end_load_slot(pf ? 16 : 0);
-      mma(1, 1);
+      run_slot(1, 1, false, std::integral_constant<int, 0>{}, 0, 0, nullptr);
       read_w(1, 1);  // W_n1 of the odd k-tile that follows
       issue(3, 0);   // A_m1(kk+2)
       end_load_slot(pf ? 16 : 0);
-      mma(1, 0);
+      run_slot(1, 0, false, std::integral_constant<int, 0>{}, 0, 0, nullptr);
       advance();
       // ================= odd k-tile (buffers 1): n order 1, 0
       read_a(1, 0);
       issue(2, 1);  // W_n1(kk+3)
       end_load_slot(pf ? 16 : 0);
-      mma(0, 1);
+      run_slot(0, 1, false, std::integral_constant<int, 0>{}, 0, 0, nullptr);
       read_w(1, 0);
       issue(0, 1);  // A_m0(kk+3)
       end_load_slot(pf ? 12 : 0);
-      mma(0, 0);
+      run_slot(0, 0, false, std::integral_constant<int, 0>{}, 0, 0, nullptr);
       // this tile's m0 half (m-tiles 0..3) is final now: stored during p2 / p3, which compute the m1 quadrants
       read_a(1, 1);
       if constexpr (F32OUT) {
@@ -1460,16 +1575,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       }
       issue(1, 1);  // W_n0(kk+3)
       end_load_slot(pf ? 8 : 0);
-      if (!F32OUT && st_cur) mma_st(1, 0, std::integral_constant<int, 0>{}, make_out(m0, n0), rs_cur);
-      else mma(1, 0);
+      run_slot(1, 0, !F32OUT && st_cur, std::integral_constant<int, 0>{}, m0, n0, rs_cur);
       read_w(0, 0);  // W_n0 of the even k-tile that follows
       if constexpr (F32OUT) {
         if (st_cur) pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 2, patch, make_out(m0, n0), lane, nullptr);
       }
       issue(3, 1);  // A_m1(kk+3)
       end_load_slot((pf ? 4 : 0) + (lf ? 4 : 0));
-      if (!F32OUT && st_cur) mma_st(1, 1, std::integral_constant<int, 2>{}, make_out(m0, n0), rs_cur);
-      else mma(1, 1);
+      run_slot(1, 1, !F32OUT && st_cur, std::integral_constant<int, 2>{}, m0, n0, rs_cur);
       if (last) zero_half(0);
       advance();
     }
@@ -1494,9 +1607,24 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     if (keep == 123.456f) reinterpret_cast<float*>(ep.C)[0] = keep;
   } else {
     const float* rs_prev = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128 : nullptr;
-    const PPOut o = make_out(pm0, pn0);
-    pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, smem + wave * 4096, o, lane, rs_prev);
-    pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, smem + wave * 4096, o, lane, rs_prev);
+    if constexpr (EPI == GRAM_EPI_KV_BANK) {
+      const bool vt = kv_is_vt(pn0);
+#pragma unroll
+      for (int J0 = 4; J0 < 8; J0 += 2) {
+        if (pm0 + wr * 128 + J0 * 16 < M) {
+          const KVLoc q = kv_locate(pm0, pn0, J0);
+#pragma unroll
+          for (int pc = 0; pc < 8; ++pc) {
+            if (vt) kv_direct(std::true_type{}, q, pc >> 2, pc & 3, acc[pc & 3][J0 + (pc >> 2)], r16, g);
+            else kv_direct(std::false_type{}, q, pc >> 2, pc & 3, acc[pc & 3][J0 + (pc >> 2)], r16, g);
+          }
+        }
+      }
+    } else {
+      const PPOut o = make_out(pm0, pn0);
+      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, smem + wave * 4096, o, lane, rs_prev);
+      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, smem + wave * 4096, o, lane, rs_prev);
+    }
   }
 }
 
@@ -1506,9 +1634,12 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
   if (N % 256 || (K / BK) % 2 || K / BK < 4 || (ep.ss_in && ep.ss_nblk != 0)) return GRAM_E_ARG;
   if ((size_t)256 * lda * 2 >= (1ull << 31) || (size_t)256 * K * 2 >= (1ull << 31) || (size_t)256 * ep.ldc * 4 >= (1ull << 31))
     return GRAM_E_ARG;  // per-tile 32-bit offsets
-  if constexpr (EPI == GRAM_EPI_KV_BANK || EPI == GRAM_EPI_F32_LSE) {
+  if constexpr (EPI == GRAM_EPI_F32_LSE) {
     return GRAM_E_ARG;
   } else {
+    if constexpr (EPI == GRAM_EPI_KV_BANK) {  // a tile inside one layer's K or V block, 32-row blocks inside one passage
+      if (ep.inner % 256 || ((ep.pmap ? ep.pL : ep.S) % 32) || M % 32) return GRAM_E_ARG;
+    }
     const int ntiles = (N / 256) * ((M + 255) / 256);
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -1587,7 +1718,8 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
       // declines shapes it does not cover (GRAM_E_ARG) and those run on the plain persistent kernel
       static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
       if (use_pp && g_force_variant < 0 &&
-          (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || (EPI == GRAM_EPI_F32_ADD && K >= 2048 && use_pp >= 2))) {
+          (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || (EPI == GRAM_EPI_KV_BANK && use_pp != 3) ||
+           (EPI == GRAM_EPI_F32_ADD && K >= 2048 && use_pp == 2))) {
         const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
         if (r != GRAM_E_ARG) return r;
       }

@@ -126,6 +126,64 @@ def test_gemm_kv_bank(G):
     assert torch.allclose(vt.float(), ref[:, :, :, 1].permute(2, 0, 3, 4, 1), atol=2e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("compact", [False, True])
+def test_gemm_kv_bank_persistent(G, compact):
+    """KV-bank epilogue of the persistent kernels (8: 2-byte V^T scatter; 22: K rows through LDS, V^T from
+    operand-swapped MFMAs) at a size with several tiles per workgroup, with and without the passage map of a
+    compacted encoder batch (+ an M tail)."""
+    from gram_amd import _lib
+    L_ = G.lib()
+    layers, H, d = 2, 4, 256
+    inner = H * 64
+    pN, pL = 4, 64
+    S = pN * pL
+    if compact:
+        B = 60
+        gen = torch.Generator().manual_seed(5)
+        keep = torch.rand(B * pN, generator=gen) < 0.85
+        keep[0] = True
+        pmap = torch.nonzero(keep).flatten().to(torch.int32)
+        P = int(pmap.numel())
+        if (P * pL) % 256 == 0:  # make sure there is an M tail
+            pmap, P = pmap[:-1], P - 1
+        M = P * pL
+    else:
+        B = 66
+        M, pmap = B * S, None
+    A = G.bf(_r(M, d, seed=41))
+    W = G.bf(_r(layers * 2 * inner, d, seed=42, scale=d ** -0.5))
+    ref = (A.float() @ W.float().T).view(M, layers, 2, H, 64)
+    res = {}
+    try:
+        for v in (8, 22):
+            L_.gram_debug_set_gemm_variant(v)
+            k = torch.zeros(layers, B, H, S, 64, dtype=torch.bfloat16, device=G.DEV)
+            vt = torch.zeros(layers, B, H, 64, S, dtype=torch.bfloat16, device=G.DEV)
+            if compact:
+                pm = pmap.to(G.DEV)
+                bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, B, H, S, pm.data_ptr(), pN, pL)
+            else:
+                bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, B, H, S)
+            G.gemm(A, W, _lib.EPI_KV_BANK, None, bank)
+            torch.cuda.synchronize()
+            res[v] = (k, vt)
+    finally:
+        L_.gram_debug_set_gemm_variant(-1)
+    # where row m of A lives in the bank
+    rows = torch.arange(M, device=G.DEV)
+    if compact:
+        flat = pmap.to(G.DEV).long()[rows // pL]
+        b_idx, s_idx = flat // pN, (flat % pN) * pL + rows % pL
+    else:
+        b_idx, s_idx = rows // S, rows % S
+    for v, (k, vt) in res.items():
+        kk = k.float()[:, b_idx, :, s_idx]        # advanced indices split by a slice: result is [M, layers, H, 64]
+        vv = vt.float()[:, b_idx, :, :, s_idx]    # [M, layers, H, 64]
+        assert torch.allclose(kk, ref[:, :, 0], atol=2e-2, rtol=1e-2), v
+        assert torch.allclose(vv, ref[:, :, 1], atol=2e-2, rtol=1e-2), v
+    assert torch.equal(res[8][0], res[22][0]) and torch.equal(res[8][1], res[22][1])
+
+
 # ------------------------------------------------------------------------------------ row ops
 def test_embed_rmsnorm_lse(G):
     L_ = G.lib()
