@@ -1,5 +1,5 @@
-"""CPU (hipcc cross-compiles): no kernel may contain the packed-fp32 self-overwrite pattern that once
-produced silently wrong cross-attention outputs (see tools/check_isa_hazards.py)."""
+"""CPU (hipcc cross-compiles): the attention kernels must not contain the packed-fp32 pattern that coincided with
+silently wrong cross-attention outputs once (a tripwire, see tools/check_isa_hazards.py; elsewhere hits are notes)."""
 import glob
 import os
 import shutil

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Scan the gfx950 ISA of every kernel in gram_amd/csrc for a packed-fp32 self-overwrite pattern.
+"""Scan the gfx950 ISA of the kernels in gram_amd/csrc for packed-fp32 instructions whose destination pair
+overlaps the register its HIGH lane reads (`v_pk_{mul,add,fma}_f32 vD[lo:hi], ..., vD... op_sel_hi:[..,0]`).
 
-`v_pk_{mul,add,fma}_f32 vD[lo:hi], ...` executes its low lane before its high lane; if the register the
-HIGH lane reads (a source's low register when that operand is broadcast with op_sel_hi = 0, or its high
-register otherwise) is the destination's LOW register, the high lane sees the low lane's result.  hipcc
-(ROCm 7.2) emitted exactly one such instruction in the cross-attention kernel (wrong outputs, no fault).
-Usage: tools/check_isa_hazards.py [file.hip ...]  -> exit status 1 if any hazard is found."""
+History: one build of the cross-attention kernel produced wrong outputs (no fault) and differed from a
+correct build by exactly one such instruction, so the pattern is kept as a TRIPWIRE for that kernel
+(dec_attn.hip: a hit fails the CPU test-suite).  tools/probes/pk_mul_self.hip later showed that the
+instruction form by itself executes correctly on MI355X (64/64 lanes), and the ping-pong GEMM contains it
+while matching the other GEMM kernel bit for bit -- so elsewhere a hit is reported as a note, and what
+guards those kernels is their parity tests.
+Usage: tools/check_isa_hazards.py [file.hip ...]  -> exit status 1 if a STRICT file (dec_attn.hip) has a hit."""
 import glob
 import os
 import re
@@ -36,7 +39,10 @@ def scan_asm(path):
     return found
 
 
-def main(files):
+STRICT = ("dec_attn",)
+
+
+def main(files, strict=STRICT):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     bad = []
     with tempfile.TemporaryDirectory() as tmp:
@@ -46,10 +52,11 @@ def main(files):
                             "-save-temps=obj"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=os.path.dirname(f))
             for asm in glob.glob(os.path.join(tmp, base + "-hip-amdgcn-*.s")):
                 bad += [(base,) + h for h in scan_asm(asm)]
+    fatal = [b for b in bad if b[0] in strict]
     for b in bad:
-        print("HAZARD", *b)
-    print(f"{len(files)} files scanned, {len(bad)} hazards")
-    return 1 if bad else 0
+        print("HAZARD" if b[0] in strict else "note", *b)
+    print(f"{len(files)} files scanned, {len(bad)} pattern hits, {len(fatal)} in strict files {strict}")
+    return 1 if fatal else 0
 
 
 if __name__ == "__main__":
