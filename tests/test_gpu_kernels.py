@@ -48,7 +48,8 @@ def test_gemm_epilogues(G, M, N, K):
     assert torch.allclose(acc, base + ref, atol=1e-3, rtol=1e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (256 * 40 + 100, 2304, 768), (256 * 86, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (256 * 40 + 100, 2304, 768), (256 * 86, 768, 3072), (520, 512, 512),
+                                   (600, 1024, 1024), (129, 256, 4096)])
 def test_gemm_persistent_variants(G, M, N, K):
     """The two persistent 256x256 kernels (8 = DMA-interleaved, 22 = ping-pong 8-phase) on every epilogue they
     implement: several tiles per workgroup (> 256 tiles), an M tail, and the folded-T5LayerNorm arguments
