@@ -191,7 +191,7 @@ def main():
         gm, xa = kernel["gemm"], kernel["cross_attn"]
         gemm_tf = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
         xa_gbs = xa["work"] / (xa["ms"] * 1e-3) / 1e9 if xa["ms"] > 0 else 0.0
-        roof_gemm = {"kernel": "gemm_il_kernel + gemm_dma_kernel (every Linear of the path; all launches in the timed region)", "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TF,
+        roof_gemm = {"kernel": "gemm_pp_kernel + gemm_il_kernel + gemm_dma_kernel (every Linear of the path; all launches in the timed region)", "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_BF16_PEAK_TF,
                      "unit": "TFLOP/s", "frac": gemm_tf / MFMA_BF16_PEAK_TF, "traffic": None,
                      "launches": gm["launches"], "avg_launch_us": 1e3 * gm["ms"] / max(gm["launches"], 1),
                      "share_of_kernel_time": gm["ms"] / max(sum(v["ms"] for v in kernel.values()), 1e-9)}
@@ -200,6 +200,25 @@ def main():
                    "avg_launch_us": 1e3 * xa["ms"] / max(xa["launches"], 1),
                    "algorithmic_bytes_per_launch": xa["work"] / max(xa["launches"], 1),
                    "share_of_kernel_time": xa["ms"] / max(sum(v["ms"] for v in kernel.values()), 1e-9)}
+        # calibration: what a plain streaming read reaches on THIS box (4 GiB swept once per launch by every CU)
+        try:
+            from gram_amd import _lib as _L
+            probe = torch.empty(4 << 30, dtype=torch.uint8, device=dev).fill_(1)
+            st_ = torch.cuda.current_stream().cuda_stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            _L.check(_L.load().gram_debug_stream_read(probe.data_ptr(), probe.numel(), None, st_), "stream_read")
+            e0.record()
+            for _ in range(3):
+                _L.check(_L.load().gram_debug_stream_read(probe.data_ptr(), probe.numel(), None, st_), "stream_read")
+            e1.record()
+            torch.cuda.synchronize()
+            sweep = 3 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            roof_xa["stream_read_gbs_this_box"] = round(sweep, 1)
+            roof_xa["frac_of_stream_read"] = round(xa_gbs / sweep, 4)
+            del probe
+        except Exception as ex:  # the probe is informational
+            roof_xa["stream_read_gbs_this_box"] = None
+            roof_xa["stream_read_error"] = str(ex)[:100]
         # HBM traffic per launch from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate rocprofv3 passes of this
         # same command, gfx950 correction applied; profiles/*_pmc_traffic.json) -- only for the matching batch size
         try:

@@ -93,6 +93,7 @@ SIGNATURES = {
     "gram_encode_fused": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, C.c_int, vp, vp]),
     "gram_decode_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
     "gram_debug_set_gemm_variant": (C.c_int, [C.c_int]),
+    "gram_debug_stream_read": (C.c_int, [vp, C.c_size_t, vp, vp]),
     "gram_prof_enable": (C.c_int, [C.c_uint32, C.c_int]),
     "gram_prof_reset": (C.c_int, []),
     "gram_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64)]),

@@ -18,6 +18,7 @@
 #ifndef GRAM_HIP_H
 #define GRAM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -309,6 +310,10 @@ int gram_prof_collect(int kind, double* total_ms, int64_t* launches, double* wor
 /* Tuning hook: force a GEMM staging variant (0 = register-staged double buffer, 1 = LDS-DMA
  * single buffer, -1 = automatic per problem size).  Used by tests/bench_gemm.py. */
 int gram_debug_set_gemm_variant(int variant);
+
+/* Calibration probe (bench.py): one streaming read of `bytes` (16-B aligned) through every CU; nothing is
+ * written unless a 32-bit fold of the data hits one magic value (sink may be NULL). */
+int gram_debug_stream_read(const void* src, size_t bytes, void* sink, void* stream);
 
 int gram_abi_version(void);
 
