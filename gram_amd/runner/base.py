@@ -114,17 +114,24 @@ class BaseRunner:
         ranks = np.concatenate(ranks) if ranks else np.zeros(0, dtype=np.int16)
         return ranks, total_time, examples, user_ids, rows_out
 
-    def _write_preds(self, fname, user_ids, ranks, rows_out):
-        """Preds TSV, single_runner_gram.py:580-588,675-694 (columns = all metrics, then gold,
-        '||'-joined predictions, '||'-joined scores)."""
+    # the reference writes this literal header whatever `metrics` is (single_runner_gram.py:588, distributed :720)
+    PRED_HEADER = "idx\tH@5\tH@10\tNDCG@5\tNDCG@10\tgold\tpred\tscores\n"
+
+    def _write_preds(self, fname, user_ids, ranks, rows_out, footer=None):
+        """Preds TSV, single_runner_gram.py:580-588,675-694,709-710: the literal header, one row per user (id, the
+        per-user metric values tab-joined, gold, '||'-joined predictions, '||'-joined scores) and, when `footer` is
+        given, the reference's closing `metric: value` lines (plain floats here; the reference prints 0-d tensors)."""
         K = self.generate_num
-        os.makedirs(os.path.dirname(fname), exist_ok=True)
+        os.makedirs(os.path.dirname(os.path.abspath(fname)), exist_ok=True)
         with open(fname, "w") as f:
-            f.write("idx\t" + "\t".join(self.metrics) + "\tgold\tpred\tscores\n")
+            f.write(self.PRED_HEADER)
             for uid, r, (gold, gen, sc) in zip(user_ids, ranks, rows_out):
                 per = evaluate.metrics_from_ranks([r], self.metrics, K)
                 f.write("\t".join([str(uid), "\t".join(str(x) for x in per), str(gold), "||".join(map(str, gen)),
                                    "||".join(str(s) for s in sc)]) + "\n")
+            if footer is not None:
+                for name, val in zip(self.metrics, footer):
+                    f.write(f"{name}: {val}\n")
 
     def test_from_model(self, rec_model_path=None, id_model_path=None):
         self.model.eval()

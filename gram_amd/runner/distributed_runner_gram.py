@@ -84,7 +84,7 @@ class DistributedRunnerGRAM(BaseRunner):
             dist.barrier()
             if self.rank == 0:  # merge per-rank files, distributed_runner_gram.py:853-874
                 with open(base, "w") as out:
-                    out.write("idx\t" + "\t".join(self.metrics) + "\tgold\tpred\tscores\n")
+                    out.write(self.PRED_HEADER)
                     import os
                     for r in range(dist.get_world_size()):
                         part = f"{base}.{r}"

@@ -25,7 +25,7 @@ class SingleRunnerGRAM(BaseRunner):
         logging.info(f"Total inference time: {total_time:.2f}s for {n_batches} samples. Average: {total_time / n_batches:.4f}s")
         if _arg(self.args, "save_predictions", False):
             self._write_preds(_arg(self.args, "pred_path", f"../preds/{testloader.dataset.dataset}_pred_{mode}.tsv"), user_ids,
-                              ranks, rows_out)
+                              ranks, rows_out, footer=metrics_res.tolist())
         self.last_results = dict(metrics=dict(zip(self.metrics, metrics_res.tolist())), sums=sums, total=test_total,
                                  hit_ranks=ranks, generate_seconds=total_time,
                                  users_per_sec=test_total / total_time if total_time > 0 else float("nan"))

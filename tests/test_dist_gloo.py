@@ -105,3 +105,46 @@ def test_world2_allgather_matches_single_process(pad):
         dup = shard_indices(N_USERS, 2, 0, True) + shard_indices(N_USERS, 2, 1, True)
         ranks = np.array([single["hit_ranks"][u] for u in dup])
         assert np.allclose(s0, ev.metrics_from_ranks(ranks, ARGS.metrics.split(","), K))
+
+
+def _preds_worker(rank, world, path, pred_path):
+    dist.init_process_group("gloo", init_method=f"file://{path}", rank=rank, world_size=world)
+    try:
+        args = SimpleNamespace(**{**vars(ARGS), "save_predictions": True, "pred_path": pred_path})
+        r = DistributedRunnerGRAM(StubModel(), None, None, None, None, None, "cpu", args, rank)
+        r.test_dataset_task(Loader(shard_indices(N_USERS, world, rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_preds_tsv_single_and_world2_merge(tmp_path):
+    """Preds file (single_runner_gram.py:580-588,675-694,709-710; merge distributed_runner_gram.py:853-874): literal
+    header, one row per user, closing `metric: value` lines; the world-2 merge holds the same rows as the single run."""
+    p1 = str(tmp_path / "single.tsv")
+    args = SimpleNamespace(**{**vars(ARGS), "save_predictions": True, "pred_path": p1})
+    r = SingleRunnerGRAM(StubModel(), None, None, None, None, None, "cpu", args)
+    r.test_dataset_task(Loader(list(range(N_USERS))))
+    lines = open(p1).read().splitlines()
+    metrics = ARGS.metrics.split(",")
+    assert lines[0] == "idx\tH@5\tH@10\tNDCG@5\tNDCG@10\tgold\tpred\tscores"
+    rows, foot = lines[1:1 + N_USERS], lines[1 + N_USERS:]
+    assert [f.split(": ")[0] for f in foot] == metrics
+    assert np.allclose([float(f.split(": ")[1]) for f in foot], [r.last_results["metrics"][m] for m in metrics])
+    for row in rows:
+        cols = row.split("\t")
+        assert len(cols) == 1 + len(metrics) + 3
+        assert len(cols[-2].split("||")) == K and len(cols[-1].split("||")) == K
+        sc = [float(x) for x in cols[-1].split("||")]
+        assert sc == sorted(sc, reverse=True)
+    p2 = str(tmp_path / "merged.tsv")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_preds_worker, args=(rk, 2, str(tmp_path / "rdzv"), p2)) for rk in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    merged = open(p2).read().splitlines()
+    assert merged[0] == lines[0] and sorted(merged[1:1 + N_USERS]) == sorted(rows)
+    mfoot = merged[1 + N_USERS:]
+    assert [f.split(": ")[0] for f in mfoot] == metrics
+    assert np.allclose([float(f.split(": ")[1]) for f in mfoot], [float(f.split(": ")[1]) for f in foot], rtol=1e-12)
+    assert not os.path.exists(p2 + ".0") and not os.path.exists(p2 + ".1")
