@@ -27,6 +27,10 @@ class StubTokenizer:
     def encode(self, text):
         return self.convert_tokens_to_ids(text.split()) + [1]
 
+    def batch_decode(self, rows, skip_special_tokens=True):
+        """ids are CRCs, not invertible: decode to the id string, which keeps the equality relation the metric uses"""
+        return [" ".join(str(t) for t in r if not (skip_special_tokens and t in (0, 1))) for r in rows]
+
     def batch_encode_plus(self, texts, max_length=None, padding=False, pad_to_max_length=False, truncation=False,
                           return_tensors=None):
         rows = []

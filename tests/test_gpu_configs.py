@@ -150,3 +150,63 @@ def test_passage_compaction_is_result_neutral(gpu, monkeypatch):
     assert torch.equal(comp["sequences"].cpu(), f_seq)
     assert torch.equal(comp["sequences_scores"].cpu(), f_sc)
     assert torch.isfinite(comp["sequences_scores"]).all()
+
+
+def test_runner_end_to_end_with_collator(gpu, tmp_path):
+    """The drop-in flow of single_runner_gram.py:570-719 on the GPU path: texts -> CollatorGRAM (stub tokenizer) ->
+    DataLoader -> get_runner("single").test_dataset_task -> Trie from the candidate strings, generate, decode, metrics,
+    preds TSV.  Every prediction is a candidate, scores are sorted, the TSV metrics are what its rows imply, and
+    the top-1 agrees with the fp32 oracle run on the same collated tensors."""
+    import random
+    from types import SimpleNamespace
+
+    from torch.utils.data import DataLoader
+
+    from gram_amd.processor import CollatorGRAM
+    from gram_amd.runner import get_runner
+    from tests.stub_tokenizer import StubTokenizer
+    oc, sd, m = _model(gpu, "small", 9)
+    rng = random.Random(3)
+    words = [f"w{i}" for i in range(60)]
+    items = sorted({" | ".join(rng.choice(words) for _ in range(3)) for _ in range(40)})
+    users = []
+    for u in range(6):
+        hist = [f"item: {rng.choice(items)} , similar items: {rng.choice(items)}" for _ in range(rng.randint(1, 4))]
+        users.append({"input": [f"what would user purchase after {' ; '.join(hist[:2])} ?"] + hist, "output": rng.choice(items),
+                      "user_id": f"U{u}"})
+    K = 5
+    args = SimpleNamespace(item_prompt_max_len=64, target_max_len=16, max_his=4, item_id_type="split", hierarchical_id_type="none",
+                           metrics="hit@1,hit@5,ndcg@5", beam_size=K, length_penalty=1.0, save_predictions=True,
+                           pred_path=str(tmp_path / "preds.tsv"))
+    tok = StubTokenizer()
+    class UserSet(list):  # the attributes the runner reads from TestDatasetGRAM
+        all_items, dataset, task = items, "Synthetic", "sequential"
+
+    loader = DataLoader(UserSet(users), batch_size=3, shuffle=False, collate_fn=CollatorGRAM(tok, args, mode="test"))
+    runner = get_runner("single", m, None, tok, None, None, None, DEV, args)
+    runner.test_dataset_task(loader)
+    res = runner.last_results
+    assert res["total"] == len(users)
+    cand_strs = {tok.batch_decode([c])[0] for c in runner.encode_candidates(items)}
+    lines = open(args.pred_path).read().splitlines()
+    rows = [ln.split("\t") for ln in lines[1:1 + len(users)]]
+    hits1 = 0
+    for r, u in zip(rows, users):
+        assert r[0] == u["user_id"]
+        preds, scores = r[-2].split("||"), [float(x) for x in r[-1].split("||")]
+        assert len(preds) == K and all(p in cand_strs for p in preds) and len(set(preds)) == K
+        assert scores == sorted(scores, reverse=True)
+        hits1 += int(preds[0] == r[-3])
+        assert float(r[1]) == float(preds[0] == r[-3])  # hit@1 column
+    assert abs(res["metrics"]["hit@1"] - hits1 / len(users)) < 1e-12
+    # top-1 against the fp32 oracle on the same collated tensors
+    enc = runner.encode_candidates(items)
+    fn = O.prefix_allowed_tokens_fn(O.Trie(enc))
+    agree, n = 0, 0
+    for batch in loader:
+        ref = O.generate(sd, oc, batch["item_text_ids"], batch["item_text_masks"], max(len(c) for c in enc), fn, K, K, 1.0)
+        ref_top = tok.batch_decode(ref["sequences"][::K].tolist())
+        for t in ref_top:
+            agree += int(t == rows[n][-2].split("||")[0])
+            n += 1
+    assert agree >= n - 1, (agree, n)
