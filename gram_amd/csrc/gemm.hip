@@ -35,7 +35,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
-enum { V_REG2 = 0, V_DMA = 1, V_DMA2 = 2, V_DMA_M256 = 3, V_DMA2_M256 = 4, V_DMA2_256SQ = 5, V_DMA_256SQ = 6, V_RING = 7, V_IL = 8, V_W4 = 13, V_PP = 22 };
+enum { V_REG2 = 0, V_DMA = 1, V_DMA2 = 2, V_DMA_M256 = 3, V_DMA2_M256 = 4, V_DMA2_256SQ = 5, V_DMA_256SQ = 6, V_RING = 7, V_IL = 8, V_PP = 22 };
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
 int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain), see gemm_il_kernel
 
@@ -755,274 +755,15 @@ int launch_il(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
 }
 
 // ---------------------------------------------------------------------------------------------
-// V_W4: persistent 256x256 tile computed by FOUR waves (one per SIMD, 512 VGPRs each), wave tile
-// 128x128 = 8x8 MFMA tiles (256 accumulator registers).  The 8-wave kernel above is bounded by LDS ->
-// register traffic: a 64x128 wave tile reads (64+128)*32*2 B = 12 KiB per 32 MFMAs, 96 KiB per k-step
-// per CU ~ 768 LDS cycles against 1024 MFMA cycles.  128x128 wave tiles read 16 KiB per 64 MFMAs =
-// 64 KiB per k-step per CU (-33 %), and the register budget allows double-buffered fragments so the
-// ds_reads of k-step s+1 overlap the MFMAs of k-step s inside the single wave each SIMD runs.
-template <int EPI>
-__device__ __forceinline__ void epilogue_rows_w4(f32x4 (&acc)[8][8], char* patch /* this wave's 16 KiB */, int m0, int n0, int wm,
-                                                 int wn, int lane, int M, const EpiArgs& ep, const float (&rs8)[8]) {
-  const int r16 = lane & 15, g = lane >> 4;
-  if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {  // 64 rows x 128 cols bf16: patch[64][256 B]
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int j = pass * 4 + jj;
-        const int row = jj * 16 + r16;
-        const float rs = rs8[j];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          f32x4 v = acc[i][j] * rs;
-          if constexpr (EPI == GRAM_EPI_BF16_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          const int chunk = (i * 2 + (g >> 1)) ^ (row & 15);
-          *reinterpret_cast<uint2*>(patch + row * 256 + chunk * 16 + (g & 1) * 8) = pack_bf16x4(v);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4), c = lane & 15;
-        const uint4 val = *reinterpret_cast<const uint4*>(patch + row * 256 + ((c ^ (row & 15)) * 16));
-        const int m = m0 + wm * 128 + pass * 64 + row;
-        if (m < M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 8) = val;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  } else {
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {  // 32 rows x 128 cols fp32: patch[32][512 B]
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = pass * 2 + jj;
-        const int row = jj * 16 + r16;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int chunk = (i * 4 + g) ^ ((row & 15) << 1);
-          *reinterpret_cast<f32x4*>(patch + row * 512 + chunk * 16) = acc[i][j];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 2 + (lane >> 5), c = lane & 31;
-        f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 512 + ((c ^ ((row & 15) << 1)) * 16));
-        const int m = m0 + wm * 128 + pass * 32 + row;
-        float ssq = 0.f;
-        if (m < M) {
-          f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4);
-          if constexpr (EPI == GRAM_EPI_F32_ADD) val += *pc;
-          *pc = val;
-          if constexpr (EPI == GRAM_EPI_F32_ADD) {
-            if (ep.xb_out) {
-              *reinterpret_cast<uint2*>(ep.xb_out + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4) = pack_bf16x4(val);
-              ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
-            }
-          }
-        }
-        if constexpr (EPI == GRAM_EPI_F32_ADD) {
-          if (ep.ss_out) {
-            ssq += __shfl_xor(ssq, 1, 64);
-            ssq += __shfl_xor(ssq, 2, 64);
-            ssq += __shfl_xor(ssq, 4, 64);
-            ssq += __shfl_xor(ssq, 8, 64);
-            if ((c & 15) == 0 && m < M) ep.ss_out[(size_t)m * ep.ss_out_nblk + ((n0 + wn * 128) >> 6) + (c >> 4)] = ssq;
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-}
-
 // LDS-DMA issued through inline asm: with the builtin, hipcc treats the DMA as an LDS store that may
 // alias every pending ds_read and puts s_waitcnt lgkmcnt(0) in front of it, which serialises the fragment
 // prefetch this kernel is built around.  The asm form is invisible to the waitcnt pass, so the kernel waits
-// for its DMA explicitly (dma_wait) before the barrier that publishes a stage.
+// for its DMA explicitly (counted s_waitcnt vmcnt) before the barrier that publishes a buffer.
 __device__ __forceinline__ void dma16_asm(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
 }
 __device__ __forceinline__ void dma4_asm(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                         int K, int lda, EpiArgs ep, int ntiles) {
-  // The k-tiles of all the tiles a workgroup walks form ONE stream: the DMA issued during k-tile s always
-  // fetches k-tile s+1 of the stream (the first k-tile of the next output tile when s is a tile's last), so
-  // the k-loop body is identical for every k-tile and the LDS stage simply alternates.
-  constexpr int TB = 256, OPB = TB * BK * 2 /*32 KiB*/, STAGE = 2 * OPB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r16 = lane & 15, g = lane >> 4;
-  const int ntn = N / TB;
-  const int G = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, local = bid >> 3, q = G >> 3, rr = G & 7;
-  const int slot = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
-  if (slot >= ntiles) return;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);  // this wave's 8 row groups of either operand
-
-  // per-lane BYTE offsets of this wave's 16 DMA pieces (8 A row groups, 8 W row groups of 8 rows x 128 B);
-  // 32-bit (the launcher checks the operands are < 4 GiB): the uniform base + k offset stays in SGPRs
-  uint32_t offA[8], offW[8];
-  auto set_tile = [&](int tile, int& m0, int& n0) {
-    const int mt = tile / ntn, nt = tile - mt * ntn;
-    m0 = mt * TB;
-    n0 = nt * TB;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = (wave * 8 + i) * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      offA[i] = ((uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + chunk * 8) * 2u;
-      offW[i] = ((uint32_t)(n0 + row) * (uint32_t)K + chunk * 8) * 2u;
-    }
-  };
-  auto dma_piece = [&](const char* gA, const char* gW, int stage, int p) {
-    const uint32_t dst = wave_lds + stage * STAGE + (p >= 8 ? OPB : 0) + (p & 7) * 1024;
-    if (p >= 8) dma16_asm(dst, offW[p & 7], gW);
-    else dma16_asm(dst, offA[p & 7], gA);
-  };
-
-  f32x4 acc[8][8];
-  bf16x8 fw[2][8], fa[2][8];
-  auto ldfrag = [&](int buf, const char* sa, const char* sw, int ks) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fw[buf][i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 128 + i * 16 + r16, ks * 4 + g));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 128 + i * 16 + r16, ks * 4 + g));
-  };
-
-  const int nkt = K / BK;
-  const char* const Ab = reinterpret_cast<const char*>(A);
-  const char* const Wb = reinterpret_cast<const char*>(W);
-  int tile = slot;
-  int m0, n0;
-  set_tile(tile, m0, n0);
-#pragma unroll
-  for (int p = 0; p < 16; ++p) dma_piece(Ab, Wb, 0, p);
-  dma_wait();
-  __syncthreads();
-  int st = 0;
-  ldfrag(0, smem, smem + OPB, 0);
-  while (true) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float rs8[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) rs8[j] = row_rscale(ep, min(m0 + wm * 128 + j * 16 + r16, M - 1));
-    if (ep.ss_in) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(rs8[j]));
-    }
-    const int cur_m0 = m0, cur_n0 = n0;
-    const int next = tile + G;
-    __syncthreads();  // every wave's epilogue patch (in the stage the first DMA below overwrites) is free again
-    for (int kt = 0; kt < nkt; ++kt) {
-      // where the next k-tile of the stream lives
-      const char *gA, *gW;
-      if (kt + 1 < nkt) {
-        gA = Ab + (kt + 1) * (BK * 2);
-        gW = Wb + (kt + 1) * (BK * 2);
-      } else {  // first k-tile of the next tile (of this tile again if there is none: harmless, keeps the body uniform)
-        set_tile(next < ntiles ? next : tile, m0, n0);
-        gA = Ab;
-        gW = Wb;
-      }
-      const char* sa = smem + st * STAGE;
-      if constexpr (ABL != 5) ldfrag(1, sa, sa + OPB, 1);
-      __builtin_amdgcn_sched_barrier(0);  // k-step-1 fragment loads go out BEFORE the k-step-0 MFMAs
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if constexpr (ABL != 1) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(fw[0][i], fa[0][j], acc[i][j]);
-        }
-        if constexpr (ABL != 2 && ABL != 5 && ABL != 6 && ABL != 7) {
-          dma_piece(gA, gW, st ^ 1, 2 * i);
-          dma_piece(gA, gW, st ^ 1, 2 * i + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (ABL != 1) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(fw[1][i], fa[1][j], acc[i][j]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);  // keep the 32 MFMAs above between the last DMA issue and its wait
-      if constexpr (ABL != 9) dma_wait();
-      if constexpr (ABL != 6 && ABL != 8) __syncthreads();  // the DMA landed; every wave has finished its LDS reads of stage st
-      st ^= 1;
-      if constexpr (ABL != 5) ldfrag(0, smem + st * STAGE, smem + st * STAGE + OPB, 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 4; i < 8; ++i) {  // hides the fragment loads above
-        if constexpr (ABL != 1) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[i][j] = mfma16(fw[1][i], fa[1][j], acc[i][j]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // st = stage of the next tile's first k-tile (its k-step-0 fragments are already in registers); the other
-    // stage is idle until the next tile's first DMA, which the barrier at the loop top orders after this epilogue
-    if constexpr (ABL == 3 || ABL >= 5) {
-      float keep = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-      if (keep == 123.456f) reinterpret_cast<float*>(ep.C)[0] = keep;
-    } else {
-      epilogue_rows_w4<EPI>(acc, smem + (st ^ 1) * STAGE + wave * 16384, cur_m0, cur_n0, wm, wn, lane, M, ep, rs8);
-    }
-    if (next >= ntiles) break;
-    tile = next;
-  }
-}
-
-template <int EPI, int ABL = 0>
-int launch_w4(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
-  constexpr int smem = 2 * 2 * 256 * 64 * 2;  // 128 KiB
-  if (N % 256) return GRAM_E_ARG;
-  if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * K * 2 >= (1ull << 32)) return GRAM_E_ARG;  // 32-bit DMA offsets
-  if constexpr (EPI == GRAM_EPI_KV_BANK || EPI == GRAM_EPI_F32_LSE) {
-    return GRAM_E_ARG;
-  } else {
-    const int ntiles = (N / 256) * ((M + 255) / 256);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GRAM_E_ARG;
-      n_cu = prop.multiProcessorCount;
-    }
-    const int nblocks = ntiles < n_cu ? ntiles : n_cu;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w4_kernel<EPI, ABL>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_w4_kernel<EPI, ABL>), dim3(nblocks), dim3(256), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda,
-                       ep, ntiles);
-    GRAM_CHECK_LAUNCH();
-    return 0;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1725,25 +1466,24 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
       }
       return launch_il<EPI>(A, W, M, N, K, lda, ep, st);
     }
-    case 9: return launch_il<EPI, 1>(A, W, M, N, K, lda, ep, st);
-    case 10: return launch_il<EPI, 2>(A, W, M, N, K, lda, ep, st);
-    case 11: return launch_il<EPI, 3>(A, W, M, N, K, lda, ep, st);
-    case 12: return launch_il<EPI, 4>(A, W, M, N, K, lda, ep, st);
-    case V_W4: return launch_w4<EPI>(A, W, M, N, K, lda, ep, st);
-    case 14: return launch_w4<EPI, 1>(A, W, M, N, K, lda, ep, st);
-    case 15: return launch_w4<EPI, 2>(A, W, M, N, K, lda, ep, st);
-    case 16: return launch_w4<EPI, 3>(A, W, M, N, K, lda, ep, st);
-    case 17: return launch_w4<EPI, 5>(A, W, M, N, K, lda, ep, st);
-    case 18: return launch_w4<EPI, 6>(A, W, M, N, K, lda, ep, st);
-    case 19: return launch_w4<EPI, 7>(A, W, M, N, K, lda, ep, st);
-    case 20: return launch_w4<EPI, 8>(A, W, M, N, K, lda, ep, st);
-    case 21: return launch_w4<EPI, 9>(A, W, M, N, K, lda, ep, st);
+    case 9: case 10: case 11: case 12:  // ablations of the DMA-interleaved kernel (bf16 epilogue only; bench_gemm.py)
+      if constexpr (EPI == GRAM_EPI_BF16) {
+        const int v = pick_variant(M, N, K);
+        return v == 9 ? launch_il<EPI, 1>(A, W, M, N, K, lda, ep, st) : v == 10 ? launch_il<EPI, 2>(A, W, M, N, K, lda, ep, st)
+             : v == 11 ? launch_il<EPI, 3>(A, W, M, N, K, lda, ep, st) : launch_il<EPI, 4>(A, W, M, N, K, lda, ep, st);
+      } else {
+        return GRAM_E_ARG;
+      }
     case V_PP: return launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
-    case 23: return launch_pp<EPI, 3>(A, W, M, N, K, lda, ep, st);
-    case 24: return launch_pp<EPI, 2>(A, W, M, N, K, lda, ep, st);
-    case 25: return launch_pp<EPI, 5>(A, W, M, N, K, lda, ep, st);
-    case 26: return launch_pp<EPI, 6>(A, W, M, N, K, lda, ep, st);
-    case 27: return launch_pp<EPI, 7>(A, W, M, N, K, lda, ep, st);
+    case 23: case 24: case 25: case 26: case 27:  // ablations of the ping-pong kernel (bf16 epilogue only)
+      if constexpr (EPI == GRAM_EPI_BF16) {
+        const int v = pick_variant(M, N, K);
+        return v == 23 ? launch_pp<EPI, 3>(A, W, M, N, K, lda, ep, st) : v == 24 ? launch_pp<EPI, 2>(A, W, M, N, K, lda, ep, st)
+             : v == 25 ? launch_pp<EPI, 5>(A, W, M, N, K, lda, ep, st) : v == 26 ? launch_pp<EPI, 6>(A, W, M, N, K, lda, ep, st)
+                                                                       : launch_pp<EPI, 7>(A, W, M, N, K, lda, ep, st);
+      } else {
+        return GRAM_E_ARG;
+      }
     default: break;
   }
   const int nblocks = (N / BN) * ((M + BM - 1) / BM);

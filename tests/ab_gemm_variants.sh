@@ -1,6 +1,6 @@
 #!/bin/bash
 # microbench of the persistent GEMM variants (+ ablations) on the encoder shapes
-#   ab_w4.sh [batch] [variants] [shapes separated by ';']
+#   ab_gemm_variants.sh [batch] [variants] [shapes separated by ';']
 set -e
 B=${1:-512}
 V=${2:-8,22,23}
