@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=2048, help="users per generate() call per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="users per generate() call per GPU")
     ap.add_argument("--backbone", default="t5-base")
     ap.add_argument("--dataset", default="Beauty")
     ap.add_argument("--passages", type=int, default=3)

@@ -1,8 +1,21 @@
+#!/bin/bash
+# One profiling pass of the default bench on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh r01e
+# writes gpurun_out/<tag>_bench.json, gpurun_out/prof_<tag>/ (kernel-trace stats) and gpurun_out/pmc_<tag>_{fetch,write}/
+# (HBM counters, one rocprofv3 pass each, never combined with a trace domain); tools/pmc_traffic.py turns the
+# counter CSVs into profiles/<tag>_pmc_traffic.json.
 set -e
-cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python bench.py > gpurun_out/r01d_bench.json 2> gpurun_out/r01d_bench.err
+TAG=${1:-round}
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout -k 10 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 echo BENCH_DONE
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r01d -o r01d -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-users 0 --no-prof > $GRAFT_REPO_ROOT/gpurun_out/r01d_prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/r01d_prof.err
-echo PROF_DONE
-ls -la $GRAFT_REPO_ROOT/gpurun_out/prof_r01d/* | head
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 3 --warmup 1 --cpu-users 0 --no-prof > $R/gpurun_out/${TAG}_prof_bench.json 2> $R/gpurun_out/${TAG}_prof.err
+echo STATS_DONE
+timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_${TAG}_fetch -o ${TAG} -- python $R/bench.py --steps 1 --warmup 1 --cpu-users 0 --no-prof > /dev/null 2> $R/gpurun_out/${TAG}_pmc_fetch.err
+echo FETCH_DONE
+timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_${TAG}_write -o ${TAG} -- python $R/bench.py --steps 1 --warmup 1 --cpu-users 0 --no-prof > /dev/null 2> $R/gpurun_out/${TAG}_pmc_write.err
+echo WRITE_DONE
+rm -f $R/gpurun_out/prof_${TAG}/*kernel_trace.csv   # (large; the stats CSV is what is kept)
+ls $R/gpurun_out/pmc_${TAG}_fetch $R/gpurun_out/pmc_${TAG}_write
