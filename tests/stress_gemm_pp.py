@@ -1,0 +1,70 @@
+"""Race screen for the ping-pong GEMM (not a pytest): a new barrier/vmcnt schedule has to be screened over many runs
+at several sizes -- an early read of a staged buffer passes whenever the DMA happens to land first.  Random shapes and
+epilogues; every output of variant 22 must equal the DMA-interleaved kernel's (variant 8) bit for bit, repeatedly.
+    python tests/stress_gemm_pp.py [seconds]"""
+import ctypes as ct
+import os
+import random
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gram_amd import _lib  # noqa: E402
+from tests import gpu_util as G  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    lib = _lib.load()
+    rng = random.Random(1234)
+    t0, n_cases, n_runs = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        K = rng.choice([256, 512, 768, 1024, 2048, 3072])
+        N = 256 * rng.randint(1, 12)
+        M = rng.choice([rng.randint(1, 600), 256 * rng.randint(1, 300) + rng.choice([0, 0, 32, 100, 255]), rng.randint(20000, 120000)])
+        epi = rng.choice([_lib.EPI_BF16, _lib.EPI_BF16_RELU, _lib.EPI_F32_ADD, _lib.EPI_F32])
+        fused = rng.random() < 0.6
+        g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
+        A = torch.randn(M, K, generator=g).to(G.DEV).to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).to(G.DEV).to(torch.bfloat16)
+        rs = (torch.rand(M, generator=g) + 0.5).to(G.DEV)
+        base = torch.randn(M, N, generator=g).to(G.DEV) if epi == _lib.EPI_F32_ADD else None
+        f32 = epi in (_lib.EPI_F32_ADD, _lib.EPI_F32)
+
+        def run(v):
+            lib.gram_debug_set_gemm_variant(v)
+            C = base.clone() if base is not None else torch.zeros(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device=G.DEV)
+            extra = []
+            if fused and epi == _lib.EPI_F32_ADD:
+                xb = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+                ss = torch.zeros(M, N // 64, dtype=torch.float32, device=G.DEV)
+                nf = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
+                extra = [xb, ss]
+            elif fused and not f32:
+                nf = _lib.NormFusion(None, None, rs.data_ptr(), 0, K, 1e-6)
+            else:
+                nf = None
+            _lib.check(lib.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(C), M, N, K, K, N, epi, None, ct.byref(nf) if nf else None,
+                                             G.stream()), "gemm")
+            torch.cuda.synchronize()
+            return [C] + extra
+
+        ref = run(8)
+        for rep in range(3):
+            got = run(22)
+            n_runs += 1
+            for a, b in zip(ref, got):
+                if not torch.equal(a, b):
+                    bad = (a.float() - b.float()).abs()
+                    print(f"MISMATCH M={M} N={N} K={K} epi={epi} fused={fused} rep={rep}: {int((bad > 0).sum())} elements, max {float(bad.max())}")
+                    sys.exit(1)
+        n_cases += 1
+        del A, W, ref, got
+    lib.gram_debug_set_gemm_variant(-1)
+    print(f"ok: {n_cases} random cases, {n_runs} ping-pong runs, all bit-identical to the reference kernel")
+
+
+if __name__ == "__main__":
+    main()
