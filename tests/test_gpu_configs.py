@@ -131,6 +131,30 @@ def test_full_size_properties_and_batch_invariance(gpu):
     assert torch.equal(o4["sequences_scores"].cpu(), scores[: 8 * K])
 
 
+@pytest.mark.parametrize("backbone,B,N,K,dataset", [("t5-small", 96, 3, 10, "Toys"), ("t5-large", 64, 4, 8, "Sports")])
+def test_batch_invariance_other_backbones(gpu, backbone, B, N, K, dataset):
+    """The big-batch kernels (ping-pong / persistent GEMMs need >= 32 768 encoder rows) at the other model widths
+    (d = 512 / 1 024, d_ff = 2 048 / 4 096, 8 / 16 heads): a user scored inside the big batch and alone (small-grid
+    kernels) gets bit-identical sequences and scores."""
+    oc = O.OracleConfig.named(backbone, max_item_num=N)
+    from gram_amd import T5Config
+    m = gpu.create_model("gram", T5Config.named(backbone, max_item_num=N))
+    m.load_state_dict(O.init_state_dict(oc, 17))
+    m = m.to(DEV).eval()
+    cands = _trie_cands(dataset)
+    g = torch.Generator().manual_seed(B)
+    ids, mask = _realistic_inputs(g, B, N, 128)
+    assert B * N * 128 >= 32768
+    out = _generate(m, ids, mask, cands, K)
+    seqs, scores = out["sequences"].cpu(), out["sequences_scores"].cpu()
+    assert torch.isfinite(scores).all()
+    for sub in ([0], [3, B - 1]):
+        o2 = _generate(m, ids[sub], mask[sub], cands, K)
+        for j, u in enumerate(sub):
+            assert torch.equal(o2["sequences"][j * K:(j + 1) * K].cpu(), seqs[u * K:(u + 1) * K][:, : o2["sequences"].shape[1]]), u
+            assert torch.equal(o2["sequences_scores"][j * K:(j + 1) * K].cpu(), scores[u * K:(u + 1) * K]), u
+
+
 def test_passage_compaction_is_result_neutral(gpu, monkeypatch):
     """Ragged batch (users padded to N = 5 with fully masked passages): running the encoder on the active
     passages only gives bit-identical sequences and scores, and the padded bank positions are never read
