@@ -333,6 +333,50 @@ __global__ __launch_bounds__(256, 2) void gemm_reg2_kernel(const bf16* __restric
   epilogue<EPI, 4>(acc, m0, n0, wm, wn, r16, g, M, ep, rs4);
 }
 
+// Row-contiguous fp32 epilogue for the 64x64 wave tiles of gemm_dma_kernel: the wave's accumulators go through a
+// 4-KiB LDS patch (the k-loop's stage is idle by then), 16 rows per pass, so the residual read-modify-write moves
+// whole 256-B row segments (and the bf16 copy whole 128-B lines) instead of 64-B / 32-B pieces.
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch /* this wave's 4 KiB */, int m0, int n0, int wm, int wn,
+                                                int lane, int M, const EpiArgs& ep) {
+  const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // patch[16][256 B], chunk c (16 B) at c ^ row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(patch + r16 * 256 + (((i * 4 + g) ^ r16) * 16)) = acc[i][j];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 4 + (lane >> 4), c = lane & 15;
+      f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16));
+      const int m = m0 + wm * 64 + j * 16 + row;
+      float ssq = 0.f;
+      if (m < M) {
+        f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 64 + c * 4);
+        if constexpr (EPI == GRAM_EPI_F32_ADD) val += *pc;
+        *pc = val;
+        if constexpr (EPI == GRAM_EPI_F32_ADD) {
+          if (ep.xb_out) {
+            *reinterpret_cast<uint2*>(ep.xb_out + (size_t)m * ep.ldc + n0 + wn * 64 + c * 4) = pack_bf16x4(val);
+            ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
+          }
+        }
+      }
+      if constexpr (EPI == GRAM_EPI_F32_ADD) {
+        if (ep.ss_out) {  // the 16 lanes of a row cover exactly one 64-column block
+          ssq += __shfl_xor(ssq, 1, 64);
+          ssq += __shfl_xor(ssq, 2, 64);
+          ssq += __shfl_xor(ssq, 4, 64);
+          ssq += __shfl_xor(ssq, 8, 64);
+          if (c == 0 && m < M) ep.ss_out[(size_t)m * ep.ss_out_nblk + ((n0 + wn * 64) >> 6)] = ssq;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int EPI, int WM, int NST, int TNW>
 __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void gemm_dma_kernel(
@@ -408,6 +452,12 @@ __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void
       if (kt + 1 < nkt) dma(kt + 1, st ^ 1);
       compute_tile<TNW>(smem + st * STAGE, smem + st * STAGE + A_BYTES, wm, wn, r16, g, acc);
       __syncthreads();  // drains DMA(kt+1) and fences the reads of stage st
+    }
+  }
+  if constexpr ((EPI == GRAM_EPI_F32_ADD || EPI == GRAM_EPI_F32) && TNW == 4 && NST == 1) {
+    if (ep.nt & 4) {  // (the last barrier of the k-loop has passed: the stage is free for the 4-KiB patches)
+      epilogue_rows64<EPI>(acc, smem + wave * 4096, m0, n0, wm, wn, lane, M, ep);
+      return;
     }
   }
   epilogue<EPI, TNW>(acc, m0, n0, wm, wn, r16, g, M, ep, rs4);
@@ -1433,6 +1483,8 @@ int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiAr
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  static const int rows_env = getenv("GRAM_GEMM_DMAROWS") ? atoi(getenv("GRAM_GEMM_DMAROWS")) : 1;  // A/B hook; measured +1.2 % end to end
+  if (rows_env) ep.nt |= 4;
   hipLaunchKernelGGL((gemm_dma_kernel<EPI, WM, NST, TNW>), dim3(nblocks), dim3(WM * 128), smem, st, (const bf16*)A, (const bf16*)W,
                      M, N, K, lda, ep);
   GRAM_CHECK_LAUNCH();
