@@ -342,10 +342,19 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
   const int r16 = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    f32x4 res[4];  // the pass's residual loads go out together, ahead of the LDS round trip (see epilogue_rows)
+    if constexpr (EPI == GRAM_EPI_F32_ADD) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = min(m0 + wm * 64 + j * 16 + it * 4 + (lane >> 4), M - 1);
+        res[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 64 + (lane & 15) * 4);
+      }
+    }
     // patch[16][256 B], chunk c (16 B) at c ^ row
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(patch + r16 * 256 + (((i * 4 + g) ^ r16) * 16)) = acc[i][j];
     __builtin_amdgcn_wave_barrier();
+    float ssq4[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 4 + (lane >> 4), c = lane & 15;
@@ -354,7 +363,7 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
       float ssq = 0.f;
       if (m < M) {
         f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 64 + c * 4);
-        if constexpr (EPI == GRAM_EPI_F32_ADD) val += *pc;
+        if constexpr (EPI == GRAM_EPI_F32_ADD) val += res[it];
         *pc = val;
         if constexpr (EPI == GRAM_EPI_F32_ADD) {
           if (ep.xb_out) {
@@ -363,13 +372,18 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
           }
         }
       }
-      if constexpr (EPI == GRAM_EPI_F32_ADD) {
-        if (ep.ss_out) {  // the 16 lanes of a row cover exactly one 64-column block
-          ssq += __shfl_xor(ssq, 1, 64);
-          ssq += __shfl_xor(ssq, 2, 64);
-          ssq += __shfl_xor(ssq, 4, 64);
-          ssq += __shfl_xor(ssq, 8, 64);
-          if (c == 0 && m < M) ep.ss_out[(size_t)m * ep.ss_out_nblk + ((n0 + wn * 64) >> 6)] = ssq;
+      ssq4[it] = ssq;
+    }
+    if constexpr (EPI == GRAM_EPI_F32_ADD) {
+      if (ep.ss_out) {  // the 16 lanes of a row cover exactly one 64-column block; 4 independent butterflies
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) ssq4[it] += __shfl_xor(ssq4[it], sh, 64);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + wm * 64 + j * 16 + it * 4 + (lane >> 4);
+          if ((lane & 15) == 0 && m < M) ep.ss_out[(size_t)m * ep.ss_out_nblk + ((n0 + wn * 64) >> 6)] = ssq4[it];
         }
       }
     }
@@ -613,12 +627,24 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[8][4], char* patch /*
     // fp32: four passes of 16 rows x 128 cols: patch[16][512 B], chunk c (16 B, 32 per row) at c ^ (row & 15)*2
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      // F32_ADD: all 8 residual loads of the pass go out FIRST (32 registers, freed accumulators later on) -- written
+      // inline below, hipcc emits load -> s_waitcnt vmcnt(0) -> store per row pair: 32 exposed HBM round trips per wave
+      f32x4 res[8];
+      if constexpr (EPI == GRAM_EPI_F32_ADD) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int m = min(m0 + wm * 64 + j * 16 + it * 2 + (lane >> 5), M - 1);  // (rows past M: loaded, never stored)
+          res[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + (lane & 31) * 4);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int chunk = (i * 4 + g) ^ ((r16 & 15) << 1);
         *reinterpret_cast<f32x4*>(patch + r16 * 512 + chunk * 16) = acc[i][j];
       }
       __builtin_amdgcn_wave_barrier();
+      float ssq8[8];  // per-lane partials of the pass; reduced across lanes AFTER the loop (8 independent butterflies
+                      // pipeline through the LDS crossbar; one per iteration was a dependent round trip each)
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int row = it * 2 + (lane >> 5), c = lane & 31;
@@ -627,7 +653,7 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[8][4], char* patch /*
         float ssq = 0.f;
         if (m < M) {
           f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4);
-          if constexpr (EPI == GRAM_EPI_F32_ADD) val += *pc;
+          if constexpr (EPI == GRAM_EPI_F32_ADD) val += res[it];
           store16(pc, val, ep.nt);
           if constexpr (EPI == GRAM_EPI_F32_ADD) {
             if (ep.xb_out) {
@@ -636,13 +662,18 @@ __device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[8][4], char* patch /*
             }
           }
         }
-        if constexpr (EPI == GRAM_EPI_F32_ADD) {
-          if (ep.ss_out) {  // 16 lanes cover one 64-column block of one row
-            ssq += __shfl_xor(ssq, 1, 64);
-            ssq += __shfl_xor(ssq, 2, 64);
-            ssq += __shfl_xor(ssq, 4, 64);
-            ssq += __shfl_xor(ssq, 8, 64);
-            if ((c & 15) == 0 && m < M) ep.ss_out[(size_t)m * ep.ss_out_nblk + ((n0 + wn * 128) >> 6) + (c >> 4)] = ssq;
+        ssq8[it] = ssq;
+      }
+      if constexpr (EPI == GRAM_EPI_F32_ADD) {
+        if (ep.ss_out) {  // 16 lanes cover one 64-column block of one row
+#pragma unroll
+          for (int sh = 1; sh < 16; sh <<= 1)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) ssq8[it] += __shfl_xor(ssq8[it], sh, 64);
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int c = lane & 31, m = m0 + wm * 64 + j * 16 + it * 2 + (lane >> 5);
+            if ((c & 15) == 0 && m < M) ep.ss_out[(size_t)m * ep.ss_out_nblk + ((n0 + wn * 128) >> 6) + (c >> 4)] = ssq8[it];
           }
         }
       }
