@@ -169,19 +169,31 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
     }
     return nsteps;
   };
+  // Two named register sets, one step ahead.  Every `load; compute` pair sits in ONE basic block with an
+  // unconditional load: with `if (more) load(...)` in front of compute(), hipcc cannot count the loads in
+  // flight at the join and waits vmcnt(0) -- i.e. also for the loads it has just issued (no overlap at all
+  // in every other iteration).
   StepRegs ra, rb;
   int i = next(-1);
-  if (i < nsteps) load(ra, i);
-  while (i < nsteps) {
+  if (i < nsteps) {
+    load(ra, i);
     int nx = next(i);
-    if (nx < nsteps) load(rb, nx);
-    compute(ra);
-    i = nx;
-    if (i >= nsteps) break;
-    nx = next(i);
-    if (nx < nsteps) load(ra, nx);
-    compute(rb);
-    i = nx;
+    while (true) {
+      if (nx >= nsteps) {
+        compute(ra);
+        break;
+      }
+      load(rb, nx);
+      compute(ra);
+      i = next(nx);
+      if (i >= nsteps) {
+        compute(rb);
+        break;
+      }
+      load(ra, i);
+      compute(rb);
+      nx = next(i);
+    }
   }
 
   // merge the four waves' partials
