@@ -34,14 +34,24 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
   const size_t rs = (size_t)3 * inner;  // qkv row stride (elements)
   const bf16* base = qkv + (size_t)p * L * rs + h * 64;
 
-  for (int i = tid; i < L * 8; i += 256) {
-    const int row = i >> 3, c = i & 7;
-    const bf16* src = base + (size_t)row * rs + c * 8;
-    bf16x8 kv = ld_global_b128(src + inner);
-    *reinterpret_cast<bf16x8*>(ks + kswz(row, c)) = kv;
-    bf16x8 vv = ld_global_b128(src + 2 * inner);
+  // K and V rows -> LDS: all 2*NKS 16-byte loads of a thread go out first (written as load; store per iteration,
+  // hipcc waits for each pair before issuing the next: NKS exposed HBM round trips per workgroup)
+  {
+    bf16x8 kv[NKS], vv[NKS];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(vts + vtswz(c * 8 + e, row)) = vv[e];
+    for (int it = 0; it < NKS; ++it) {
+      const int i = tid + it * 256, row = i >> 3, c = i & 7;
+      const bf16* src = base + (size_t)row * rs + c * 8;
+      kv[it] = ld_global_b128(src + inner);
+      vv[it] = ld_global_b128(src + 2 * inner);
+    }
+#pragma unroll
+    for (int it = 0; it < NKS; ++it) {
+      const int i = tid + it * 256, row = i >> 3, c = i & 7;
+      *reinterpret_cast<bf16x8*>(ks + kswz(row, c)) = kv[it];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(vts + vtswz(c * 8 + e, row)) = vv[it][e];
+    }
   }
   if (tid < 255) bias_s[tid] = bias[h * 255 + tid];
   if (tid < L) mask_s[tid] = mask[(size_t)p * L + tid] ? 0.f : 1.f;
