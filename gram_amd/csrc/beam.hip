@@ -166,7 +166,20 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
       if (act) {
         const bf16* hp = hd + (size_t)lr * d + sub * per;
         const bf16* ep = emb + (size_t)tok * d + sub * per;
-        for (int i = 0; i < per; i += 8) {
+        int i = 0;
+        for (; i + 32 <= per; i += 32) {  // 8 loads in flight per lane (one load pair per iteration is a dependent round trip each)
+          bf16x8 hv[4], ev[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            hv[u] = ld_global_b128(hp + i + 8 * u);
+            ev[u] = ld_global_b128(ep + i + 8 * u);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += (float)hv[u][e] * (float)ev[u][e];  // same order as the scalar loop
+        }
+        for (; i < per; i += 8) {
           const bf16x8 hv = ld_global_b128(hp + i), ev = ld_global_b128(ep + i);
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc += (float)hv[e] * (float)ev[e];
