@@ -1093,7 +1093,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // bf16 epilogues: an MFMA slot that also stores the 32 finished rows of m-tiles J0, J0+1 (not the quadrant being
   // computed).  Scale/convert/ds_write pieces fill the issue gaps of the first 8 MFMAs, the patch reads those of
   // the next 4, and the 4 row-contiguous global stores go out behind the last MFMA, so the slot is barely longer.
-  auto mma_st = [&](int mq, int nq, auto TRc, auto J0c, const PPOut& o, const float* rs) {
+  auto mma_st = [&](int mq, int nq, auto TRc, auto J0c, const PPOut& o, const float* rs, auto FULLc) {
+    constexpr bool FULL = decltype(FULLc)::value;  // all 128 rows of the wave exist: stores without a predicate (no branches in the slot)
     constexpr int J0 = decltype(J0c)::value;
     int ln = lane;
     asm volatile("" : "+v"(ln));  // opaque: no hoisting of the addresses below out of the k-loop (they would be spilled)
@@ -1119,7 +1120,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       if constexpr (ABL == 6) {
         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
       } else {
-        if (mr0 + it * 8 < o.rows) {
+        if (FULL || mr0 + it * 8 < o.rows) {
           uint4* dst = reinterpret_cast<uint4*>(o.c + (voff0 + (uint32_t)(it * 8) * o.ldc_b));
           // streaming (nt) store: the output is far larger than L2 and is next read by another kernel; keeping it
           // out of L2 leaves the A panels this XCD re-reads there (measured +1.6 ... 4 %)
@@ -1316,14 +1317,18 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       if (tr_cur) {
         if (!job) mma(mq, nq, std::true_type{});
         else if (vt) mma_vt(mq, nq, std::true_type{}, J0c, q);
-        else mma_st(mq, nq, std::true_type{}, J0c, kv_out_k(q, tm0, J0), nullptr);
+        else mma_st(mq, nq, std::true_type{}, J0c, kv_out_k(q, tm0, J0), nullptr, std::false_type{});
       } else {
         if (!job) mma(mq, nq, std::false_type{});
         else if (vt) mma_vt(mq, nq, std::false_type{}, J0c, q);
-        else mma_st(mq, nq, std::false_type{}, J0c, kv_out_k(q, tm0, J0), nullptr);
+        else mma_st(mq, nq, std::false_type{}, J0c, kv_out_k(q, tm0, J0), nullptr, std::false_type{});
       }
     } else {
-      if (job) mma_st(mq, nq, std::false_type{}, J0c, make_out(tm0, tn0), rs);
+      if (job) {
+        const PPOut o = make_out(tm0, tn0);
+        if (o.rows >= 128) mma_st(mq, nq, std::false_type{}, J0c, o, rs, std::true_type{});
+        else mma_st(mq, nq, std::false_type{}, J0c, o, rs, std::false_type{});
+      }
       else mma(mq, nq, std::false_type{});
     }
   };
