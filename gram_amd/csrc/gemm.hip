@@ -60,7 +60,12 @@ struct EpiArgs {
   const int32_t* pmap;  // compacted encoder rows: passage p = m / pL is flat passage pmap[p] = b*pN + n (NULL: identity)
   int pL, pN;
   int nt;  // streaming (nt) stores in the persistent kernel's row-contiguous epilogue (A/B hook GRAM_GEMM_NT)
+  // ping-pong KV-bank epilogue: divisions by runtime values as multiply-high (scalar ALU; a division sequence costs
+  // a dozen VGPRs the kernel does not have).  mg_x = floor(2^32 / x) + 1; exact for the dividends documented at use.
+  uint32_t mg_pL32, mg_S32, mg_pN, mg_it;  // x = pL/32, S/32, pN, inner/256
 };
+inline uint32_t magic_u32(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t x, uint32_t d, uint32_t mg) { return d <= 1 ? x : __umulhi(x, mg); }
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -868,6 +873,10 @@ __device__ __forceinline__ void dma4_asm(uint32_t lds_addr /*wave-uniform*/, uin
 // the counted wait after each issue is s_waitcnt vmcnt(10): all but the 5 newest half-tiles (2 DMA
 // instructions per wave each) have landed, which is exactly what the NEXT phase reads.  The k-tiles of
 // all the tiles a workgroup walks form one stream, so the pipeline never drains between tiles.
+// The KV-bank GEMM runs on the ping-pong kernel as TWO launches over disjoint n-tiles: K tiles (PP_KV_K: normal MFMA operand
+// order, rows through LDS) and V^T tiles (PP_KV_V: operands the other way round, direct 8-B stores).  One instantiation
+// with both code paths spills accumulators (256 VGPRs); each half alone does not.
+constexpr int PP_KV_K = 100, PP_KV_V = 101;
 __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 // Store the wave's output rows of m-tiles j0, j0+1 (32 rows x 64 columns) through its LDS patch as whole
@@ -973,6 +982,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
                                                          int K, int lda, EpiArgs ep, int ntiles, int stagger) {
   constexpr int TB = 256, HT = 16384;
   constexpr bool F32OUT = EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD;
+  constexpr bool KV = EPI == PP_KV_K || EPI == PP_KV_V;  // n-tiles of the K blocks only / of the V blocks only
+  constexpr bool TRALL = EPI == PP_KV_V;
   // epilogue patches: fp32 outputs 8 x 4 KiB (one per wave, used in load slots); bf16 outputs 4 x 4 KiB, shared by
   // waves w and w+4 -- the two groups use them in alternate time slots (each inside its own MFMA slot)
   constexpr int PATCH = 4096;
@@ -983,7 +994,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell hipcc it is wave-uniform: everything derived stays in SGPRs
   const int wr = wave >> 2, wc = wave & 3;
   const int r16 = lane & 15, g = lane >> 4;
-  const int ntn = N / TB;
+  const int ntn = KV ? N / TB / 2 : N / TB;  // KV: this launch walks every other block of inner/256 n-tiles
+  auto nt_of = [&](int ntl) {  // launch-local n-tile -> n-tile of the GEMM
+    if constexpr (KV) {
+      const int it = ep.inner >> 8, blk = (int)udiv_magic((uint32_t)ntl, (uint32_t)it, ep.mg_it);
+      return blk * 2 * it + (TRALL ? it : 0) + (ntl - blk * it);
+    } else {
+      return ntl;
+    }
+  };
   const int G = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, local = bid >> 3, q = G >> 3, rr = G & 7;
   const int slot = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
@@ -1009,7 +1028,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     offW[p] = ((uint32_t)((r >> 5) * 64 + (r & 31)) * (uint32_t)K + chunk * 8) * 2u;
   }
   auto set_offsets = [&]() {
-    const int mt = c_tile / ntn, nt = c_tile - mt * ntn;
+    const int mt = c_tile / ntn, nt = nt_of(c_tile - mt * ntn);
     c_A = Ab + (size_t)mt * TB * lda * 2;
     c_W = Wb + (size_t)nt * TB * K * 2;
     const int mleft = M - 1 - mt * TB;  // last valid row, tile-relative
@@ -1180,22 +1199,23 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   auto kv_locate = [&](int tm0, int tn0, int J0) {
     KVLoc q;
     q.mblk = tm0 + wr * 128 + J0 * 16;
+    // mblk, pL, S are multiples of 32: (mblk/32) / (x/32), dividend < 2^25 and divisor <= 128 -> multiply-high is exact
+    // (error term < divisor, dividend * error < 2^32); flat < 2^27 with pN <= 22 likewise; n-tiles < 2^16 by inner/256
     int b_, s0;
     if (ep.pmap) {
-      const int pp = q.mblk / ep.pL, l = q.mblk - pp * ep.pL, flat = ep.pmap[pp];
-      b_ = flat / ep.pN;
+      const int pp = (int)udiv_magic((uint32_t)q.mblk >> 5, (uint32_t)ep.pL >> 5, ep.mg_pL32), l = q.mblk - pp * ep.pL, flat = ep.pmap[pp];
+      b_ = (int)udiv_magic((uint32_t)flat, (uint32_t)ep.pN, ep.mg_pN);
       s0 = (flat - b_ * ep.pN) * ep.pL + l;
     } else {
-      b_ = q.mblk / ep.S;
+      b_ = (int)udiv_magic((uint32_t)q.mblk >> 5, (uint32_t)ep.S >> 5, ep.mg_S32);
       s0 = q.mblk - b_ * ep.S;
     }
-    const int n = tn0 + wc * 64, lw = n / ep.inner;
+    const int n = tn0 + wc * 64, lw = (int)udiv_magic((uint32_t)n >> 8, (uint32_t)ep.inner >> 8, ep.mg_it);
     const size_t head = ((size_t)(lw >> 1) * ep.B + b_) * ep.H + ((n - lw * ep.inner) >> 6);
     q.kb = reinterpret_cast<char*>(ep.bank_k + (head * ep.S + s0) * 64);
     q.vb = reinterpret_cast<char*>(ep.bank_vt + head * 64 * ep.S + s0);
     return q;
   };
-  auto kv_is_vt = [&](int tn0) { return (int)((tn0 / ep.inner) & 1); };
   // one (m-tile jj, n-tile pi) fragment of the block straight from registers (8 B per lane)
   // (wave-uniform base + 32-bit per-lane offset)
   auto kv_direct = [&](auto TRc, const KVLoc& q, int jj, int pi, const f32x4& v, int lr, int lg) {
@@ -1236,7 +1256,6 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     o.rows = M - (tm0 + wr * 128);
     return o;
   };
-  bool tr_cur = false;  // KV bank: the tile being computed is a V^T tile
   // extra = number of epilogue stores this wave has issued since the DMA that must have landed (a lower bound is
   // always safe: vmcnt counts loads, stores and DMA together, in issue order)
   auto end_load_slot = [&](int extra = 0) {
@@ -1304,24 +1323,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // one MFMA slot of quadrant (mq, nq), optionally with the epilogue job "store m-tiles J0, J0+1 of tile (tm0, tn0)"
   auto run_slot = [&](int mq, int nq, bool job, auto J0c, int tm0, int tn0, const float* rs) {
     constexpr int J0 = decltype(J0c)::value;
-    if constexpr (EPI == GRAM_EPI_KV_BANK) {
-      KVLoc q{};
-      bool vt = false;
-      if (job) {
-        job = tm0 + wr * 128 + J0 * 16 < M;  // (a block past the M tail: nothing to store, and no pmap entry)
-        if (job) {
-          q = kv_locate(tm0, tn0, J0);
-          vt = kv_is_vt(tn0);
-        }
-      }
-      if (tr_cur) {
-        if (!job) mma(mq, nq, std::true_type{});
-        else if (vt) mma_vt(mq, nq, std::true_type{}, J0c, q);
-        else mma_st(mq, nq, std::true_type{}, J0c, kv_out_k(q, tm0, J0), nullptr, std::false_type{});
+    if constexpr (KV) {
+      using TR = std::integral_constant<bool, TRALL>;
+      job = job && tm0 + wr * 128 + J0 * 16 < M;  // (a block past the M tail: nothing to store, and no pmap entry)
+      if (!job) {
+        mma(mq, nq, TR{});
       } else {
-        if (!job) mma(mq, nq, std::false_type{});
-        else if (vt) mma_vt(mq, nq, std::false_type{}, J0c, q);
-        else mma_st(mq, nq, std::false_type{}, J0c, kv_out_k(q, tm0, J0), nullptr, std::false_type{});
+        const KVLoc q = kv_locate(tm0, tn0, J0);
+        if constexpr (TRALL) mma_vt(mq, nq, TR{}, J0c, q);
+        else mma_st(mq, nq, TR{}, J0c, kv_out_k(q, tm0, J0), nullptr, std::false_type{});
       }
     } else {
       if (job) {
@@ -1337,19 +1347,18 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   zero_half(1);
   while (true) {
     {
-      const int mt = tile / ntn, nt = tile - mt * ntn;
+      const int mt = tile / ntn, nt = nt_of(tile - mt * ntn);
       m0 = mt * TB;
       n0 = nt * TB;
     }
-    if constexpr (EPI == GRAM_EPI_KV_BANK) tr_cur = kv_is_vt(n0);
     const float* rs_cur = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + tpar * 256 + wr * 128 : nullptr;
     const float* rs_prev = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128 : nullptr;
     for (int kt = 0; kt < nkt; kt += 2) {
       const bool first = kt == 0, last = kt + 2 >= nkt;
       // bf16 epilogues of FULL tiles issue exactly 4 stores per store slot (the slots p2, p3 of a tile's last k-tile
       // and p0, p1 of the next tile's first): pf / lf = such stores were / are issued around this k-tile pair
-      const bool pf = !F32OUT && EPI != GRAM_EPI_KV_BANK && STORES && first && pending && M - (pm0 + wr * 128) >= 128;
-      const bool lf = !F32OUT && EPI != GRAM_EPI_KV_BANK && STORES && last && M - (m0 + wr * 128) >= 128;
+      const bool pf = !F32OUT && !KV && STORES && first && pending && M - (pm0 + wr * 128) >= 128;
+      const bool lf = !F32OUT && !KV && STORES && last && M - (m0 + wr * 128) >= 128;
       // ================= even k-tile (buffers 0): n order 0, 1
       // Epilogue of the previous tile's m1 half (m-tiles 4..7, finished by its last MFMA slot): fp32 outputs store it
       // in the load slots of p0 / p1, bf16 outputs inside the MFMA slots of p0 / p1 (which compute m0 quadrants).
@@ -1434,17 +1443,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     if (keep == 123.456f) reinterpret_cast<float*>(ep.C)[0] = keep;
   } else {
     const float* rs_prev = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128 : nullptr;
-    if constexpr (EPI == GRAM_EPI_KV_BANK) {
-      const bool vt = kv_is_vt(pn0);
+    if constexpr (KV) {
 #pragma unroll
       for (int J0 = 4; J0 < 8; J0 += 2) {
         if (pm0 + wr * 128 + J0 * 16 < M) {
           const KVLoc q = kv_locate(pm0, pn0, J0);
 #pragma unroll
-          for (int pc = 0; pc < 8; ++pc) {
-            if (vt) kv_direct(std::true_type{}, q, pc >> 2, pc & 3, acc[pc & 3][J0 + (pc >> 2)], r16, g);
-            else kv_direct(std::false_type{}, q, pc >> 2, pc & 3, acc[pc & 3][J0 + (pc >> 2)], r16, g);
-          }
+          for (int pc = 0; pc < 8; ++pc)
+            kv_direct(std::integral_constant<bool, TRALL>{}, q, pc >> 2, pc & 3, acc[pc & 3][J0 + (pc >> 2)], r16, g);
         }
       }
     } else {
@@ -1457,6 +1463,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
 
 template <int EPI, int ABL = 0>
 int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+  if constexpr (EPI == GRAM_EPI_KV_BANK) {  // the public id: both halves, one launch each (no kernel of its own)
+    const int r = launch_pp<PP_KV_K, ABL>(A, W, M, N, K, lda, ep, st);
+    return r ? r : launch_pp<PP_KV_V, ABL>(A, W, M, N, K, lda, ep, st);
+  } else {
   constexpr int smem = 8 * 16384 + 8 * 4096;  // 160 KiB
   if (N % 256 || (K / BK) % 2 || K / BK < 4 || (ep.ss_in && ep.ss_nblk != 0)) return GRAM_E_ARG;
   if ((size_t)256 * lda * 2 >= (1ull << 31) || (size_t)256 * K * 2 >= (1ull << 31) || (size_t)256 * ep.ldc * 4 >= (1ull << 31))
@@ -1464,10 +1474,15 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
   if constexpr (EPI == GRAM_EPI_F32_LSE) {
     return GRAM_E_ARG;
   } else {
-    if constexpr (EPI == GRAM_EPI_KV_BANK) {  // a tile inside one layer's K or V block, 32-row blocks inside one passage
+    if constexpr (EPI == PP_KV_K || EPI == PP_KV_V) {  // a tile inside one layer's K or V block, 32-row blocks inside one passage
       if (ep.inner % 256 || ((ep.pmap ? ep.pL : ep.S) % 32) || M % 32) return GRAM_E_ARG;
+      if (ep.S > 4096 || (ep.pmap && (ep.pL > 4096 || ep.pN > 64 || (long)ep.B * ep.pN >= (1l << 26))) || M >= (1 << 30)) return GRAM_E_ARG;
+      ep.mg_pL32 = magic_u32(ep.pmap ? ep.pL >> 5 : 1);
+      ep.mg_S32 = magic_u32(ep.S >> 5);
+      ep.mg_pN = magic_u32(ep.pmap ? ep.pN : 1);
+      ep.mg_it = magic_u32(ep.inner >> 8);
     }
-    const int ntiles = (N / 256) * ((M + 255) / 256);
+    const int ntiles = ((EPI == PP_KV_K || EPI == PP_KV_V) ? N / 512 : N / 256) * ((M + 255) / 256);
     static int n_cu = 0;
     if (n_cu == 0) {
       int dev = 0;
@@ -1487,6 +1502,7 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
                        ep, ntiles, g_stagger);
     GRAM_CHECK_LAUNCH();
     return 0;
+  }
   }
 }
 
