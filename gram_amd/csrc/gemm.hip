@@ -1232,19 +1232,59 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // MFMA slot + the V^T block of m-tiles J0, J0+1 (computed with swapped operands): 8 direct 8-B stores per lane,
   // 16 d-rows x 32 B each (2-byte scatter in the plain kernel), issued in the gaps of the first 8 MFMAs
   auto mma_vt = [&](int mq, int nq, auto TRc, auto J0c, const KVLoc& q) {
+    // (the block exists entirely: M is a multiple of 32 and its first row is < M)
     constexpr int J0 = decltype(J0c)::value;
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int lr = ln & 15, lg = ln >> 4;
+    // V^T block = 64 columns d x 32 bank positions: through the shared 4-KiB patch as [64 d][64 B] so that a lane stores
+    // 16 B (8 positions) and a d-row 64 B, instead of 8-B pieces of 32-B segments straight from the registers.
+    //   write (m-tile jj, n-tile pi): row d = pi*16 + lr, bytes jj*32 + lg*8;   16-B chunk c of row d sits at c ^ ((d >> 2) & 3)
+    const char* const wbase = patch + lr * 64 + (lg & 1) * 8;
+    const int wsw = (lr >> 2) & 3;  // (d >> 2) & 3 = (lr >> 2) & 3: pi*16 does not change it
+    //   read it: row d = it*16 + (ln >> 2), chunk ln & 3
+    const int rd = ln >> 2, rc = ln & 3;
+    const char* const gbase = patch + rd * 64 + ((rc ^ ((rd >> 2) & 3)) * 16);
+    const uint32_t voff0 = ((uint32_t)rd * (uint32_t)ep.S + rc * 8) * 2u;
+    uint4 pv;
+    auto get = [&](int it) { return *reinterpret_cast<const uint4*>(gbase + it * 1024); };  // 16 rows = 1 KiB, swizzle term unchanged
+    auto put = [&](int it, const uint4& v) {
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v),
+                                  reinterpret_cast<u32x4*>(q.vb + (voff0 + (uint32_t)(it * 16) * (uint32_t)ep.S * 2u)));
+    };
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
       if constexpr (ABL != 1) mfma_q(TRc, mq, nq, n);
-      if (n < 8) kv_direct(std::true_type{}, q, n >> 2, n & 3, acc[n & 3][J0 + (n >> 2)], lr, lg);
+      if (n < 8 && (n & 1)) {
+#pragma unroll
+        for (int pc = n - 1; pc <= n; ++pc) {
+          const int jj = pc >> 2, pi = pc & 3;
+          const int chunk = (jj * 2 + (lg >> 1)) ^ wsw;
+          *reinterpret_cast<uint2*>(const_cast<char*>(wbase) + pi * 1024 + chunk * 16) = pack_bf16x4(acc[pi][J0 + jj]);
+        }
+      }
+      if (n == 7) __builtin_amdgcn_wave_barrier();
+      if (n == 8) pv = get(0);
+      if (n == 10) {
+        put(0, pv);
+        pv = get(1);
+      }
+      if (n == 12) {
+        put(1, pv);
+        pv = get(2);
+      }
+      if (n == 14) {
+        put(2, pv);
+        pv = get(3);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
+    put(3, pv);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the shared patch is idle before the other group's slot
     __builtin_amdgcn_sched_barrier(0);
     pp_barrier();
   };
