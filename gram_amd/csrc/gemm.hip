@@ -1404,22 +1404,16 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       // in the load slots of p0 / p1, bf16 outputs inside the MFMA slots of p0 / p1 (which compute m0 quadrants).
       const bool st_prev = STORES && first && pending, st_cur = STORES && last;
       read_a(0, 0);
-      if constexpr (F32OUT) {
-        if (st_prev) pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, patch, make_out(pm0, pn0), lane, nullptr);
-      }
       issue(1, 0);  // W_n0(kk+2)
       end_load_slot(pf ? 8 : 0);
       run_slot(0, 0, !F32OUT && st_prev, std::integral_constant<int, 4>{}, pm0, pn0, rs_prev);
       read_w(0, 1);
-      if constexpr (F32OUT) {
-        if (st_prev) pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, patch, make_out(pm0, pn0), lane, nullptr);
-      }
       issue(0, 0);  // A_m0(kk+2)
       end_load_slot(pf ? 12 : 0);
       run_slot(0, 1, !F32OUT && st_prev, std::integral_constant<int, 6>{}, pm0, pn0, rs_prev);
       read_a(0, 1);
       if (first) {
-        zero_half(1);
+        if constexpr (!F32OUT) zero_half(1);
         if (has_rs && wave < 4) {  // this tile's 256 row scales -> LDS by DMA (64 rows per wave); first read >= 6 k-tiles later
           int ln = lane;
           asm volatile("" : "+v"(ln));
@@ -1446,35 +1440,49 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       run_slot(0, 0, false, std::integral_constant<int, 0>{}, 0, 0, nullptr);
       // this tile's m0 half (m-tiles 0..3) is final now: stored during p2 / p3, which compute the m1 quadrants
       read_a(1, 1);
-      if constexpr (F32OUT) {
-        if (st_cur) pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 0, patch, make_out(m0, n0), lane, nullptr);
-      }
       issue(1, 1);  // W_n0(kk+3)
       end_load_slot(pf ? 8 : 0);
       run_slot(1, 0, !F32OUT && st_cur, std::integral_constant<int, 0>{}, m0, n0, rs_cur);
       read_w(0, 0);  // W_n0 of the even k-tile that follows
-      if constexpr (F32OUT) {
-        if (st_cur) pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 2, patch, make_out(m0, n0), lane, nullptr);
-      }
       issue(3, 1);  // A_m1(kk+3)
       end_load_slot((pf ? 4 : 0) + (lf ? 4 : 0));
       run_slot(1, 1, !F32OUT && st_cur, std::integral_constant<int, 2>{}, m0, n0, rs_cur);
-      if (last) zero_half(0);
+      if (last && !F32OUT) zero_half(0);
       advance();
+    }
+    const bool more = tile + G < ntiles;
+    if constexpr (F32OUT && STORES) {
+      // fp32 outputs: the read-modify-write epilogue runs at the END of the tile with both wave groups in step (like the
+      // other persistent kernel): inside the slots its residual loads drain the in-order DMA queue four times per tile and
+      // group; here once.  Group 0 waits for group 1's last MFMA slot, both store, and group 1 falls one barrier behind again.
+      if (wr == 0) pp_barrier();
+      const PPOut o = make_out(m0, n0);
+      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 0, patch, o, lane, nullptr);
+      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 2, patch, o, lane, nullptr);
+      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, patch, o, lane, nullptr);
+      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, patch, o, lane, nullptr);
+      zero_half(0);
+      zero_half(1);
+      pp_barrier();
+      if (more && wr == 1) pp_barrier();
     }
     pending = true;
     pm0 = m0;
     pn0 = n0;
     tpar ^= 1;
-    if (tile + G >= ntiles) break;
+    if (!more) break;
     tile += G;
   }
   // The last tile's m1 half is still in the accumulators.  Every DMA of this workgroup must have landed before it
   // ends, and after that the half-tile buffers are dead: they serve as 8 private patches for the final stores.
-  if (wr == 0) pp_barrier();
+  if constexpr (!(F32OUT && STORES)) {
+    if (wr == 0) pp_barrier();
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   pp_barrier();
-  if constexpr (!STORES) {
+  if constexpr (F32OUT && STORES) {
+    // (stored at the end of every tile)
+  } else if constexpr (!STORES) {
     float keep = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1599,12 +1607,12 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
     case V_DMA_256SQ: return launch_dma<EPI, 4, 1, 8>(A, W, M, N, K, lda, ep, st);
     case V_RING: return launch_ring<EPI>(A, W, M, N, K, lda, ep, st);
     case V_IL: {
-      // the ping-pong kernel is faster for bf16 outputs (+12 %) and for long-K fp32 residual GEMMs (+5 %); it
+      // the ping-pong kernel is faster for bf16 outputs (+15 %) and for long-K fp32 residual GEMMs (+12-15 %, tile-end epilogue); it
       // declines shapes it does not cover (GRAM_E_ARG) and those run on the plain persistent kernel
       static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
       if (use_pp && g_force_variant < 0 &&
           (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || (EPI == GRAM_EPI_KV_BANK && use_pp != 3) ||
-           (EPI == GRAM_EPI_F32_ADD && K >= 2048 && use_pp == 2))) {
+           (EPI == GRAM_EPI_F32_ADD && K >= 2048 && use_pp != 3 && use_pp != 4))) {
         const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
         if (r != GRAM_E_ARG) return r;
       }
