@@ -987,6 +987,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // epilogue patches: fp32 outputs 8 x 4 KiB (one per wave, used in load slots); bf16 outputs 4 x 4 KiB, shared by
   // waves w and w+4 -- the two groups use them in alternate time slots (each inside its own MFMA slot)
   constexpr int PATCH = 4096;
+  // TEND: the epilogue runs at the end of the tile, both wave groups in step (fp32 outputs).  ABL 7 = the same for bf16
+  // outputs (microbench variant 27): 1 035 vs 1 105 TFLOP/s for the in-slot jobs on the encoder QKV shape, so bf16 stays in-slot
+  constexpr bool TEND = (EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD) || (ABL == 7 && (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU));
   constexpr int RS_OFF = 8 * HT + 4 * 4096;  // bf16 epilogues: 2 x 1 KiB of row scales behind the patches
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 8 half-tile buffers + epilogue patches (+ row scales)
   const int tid = threadIdx.x;
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);  // this wave's 2 pieces (16 rows) of a half-tile
   const char* const Ab = reinterpret_cast<const char*>(A);
   const char* const Wb = reinterpret_cast<const char*>(W);
-  char* const patch = smem + 8 * HT + (F32OUT ? wave : (wave & 3)) * PATCH;
+  char* const patch = smem + 8 * HT + (F32OUT ? wave * PATCH : TEND ? wave * 2048 : (wave & 3) * PATCH);
   const bool has_rs = !F32OUT && ep.ss_in != nullptr;  // ss_nblk == 0 (1/rms per row), checked by the launcher
 
   // DMA cursor = stream k-tile kk+2 (tile, kt) + per-lane byte offsets of this wave's 2 pieces of each half-tile type
@@ -1144,8 +1147,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
           // streaming (nt) store: the output is far larger than L2 and is next read by another kernel; keeping it
           // out of L2 leaves the A panels this XCD re-reads there (measured +1.6 ... 4 %)
           typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-          if constexpr (ABL == 7) *dst = v;  // ablation: default cache policy
-          else __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst));
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst));
         }
       }
     };
@@ -1406,14 +1408,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       read_a(0, 0);
       issue(1, 0);  // W_n0(kk+2)
       end_load_slot(pf ? 8 : 0);
-      run_slot(0, 0, !F32OUT && st_prev, std::integral_constant<int, 4>{}, pm0, pn0, rs_prev);
+      run_slot(0, 0, !TEND && st_prev, std::integral_constant<int, 4>{}, pm0, pn0, rs_prev);
       read_w(0, 1);
       issue(0, 0);  // A_m0(kk+2)
       end_load_slot(pf ? 12 : 0);
-      run_slot(0, 1, !F32OUT && st_prev, std::integral_constant<int, 6>{}, pm0, pn0, rs_prev);
+      run_slot(0, 1, !TEND && st_prev, std::integral_constant<int, 6>{}, pm0, pn0, rs_prev);
       read_a(0, 1);
       if (first) {
-        if constexpr (!F32OUT) zero_half(1);
+        if constexpr (!TEND) zero_half(1);
         if (has_rs && wave < 4) {  // this tile's 256 row scales -> LDS by DMA (64 rows per wave); first read >= 6 k-tiles later
           int ln = lane;
           asm volatile("" : "+v"(ln));
@@ -1442,25 +1444,25 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       read_a(1, 1);
       issue(1, 1);  // W_n0(kk+3)
       end_load_slot(pf ? 8 : 0);
-      run_slot(1, 0, !F32OUT && st_cur, std::integral_constant<int, 0>{}, m0, n0, rs_cur);
+      run_slot(1, 0, !TEND && st_cur, std::integral_constant<int, 0>{}, m0, n0, rs_cur);
       read_w(0, 0);  // W_n0 of the even k-tile that follows
       issue(3, 1);  // A_m1(kk+3)
       end_load_slot((pf ? 4 : 0) + (lf ? 4 : 0));
-      run_slot(1, 1, !F32OUT && st_cur, std::integral_constant<int, 2>{}, m0, n0, rs_cur);
-      if (last && !F32OUT) zero_half(0);
+      run_slot(1, 1, !TEND && st_cur, std::integral_constant<int, 2>{}, m0, n0, rs_cur);
+      if (last && !TEND) zero_half(0);
       advance();
     }
     const bool more = tile + G < ntiles;
-    if constexpr (F32OUT && STORES) {
+    if constexpr (TEND && STORES) {
       // fp32 outputs: the read-modify-write epilogue runs at the END of the tile with both wave groups in step (like the
       // other persistent kernel): inside the slots its residual loads drain the in-order DMA queue four times per tile and
       // group; here once.  Group 0 waits for group 1's last MFMA slot, both store, and group 1 falls one barrier behind again.
       if (wr == 0) pp_barrier();
       const PPOut o = make_out(m0, n0);
-      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 0, patch, o, lane, nullptr);
-      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 2, patch, o, lane, nullptr);
-      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, patch, o, lane, nullptr);
-      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, patch, o, lane, nullptr);
+      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 0, patch, o, lane, rs_cur);
+      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 2, patch, o, lane, rs_cur);
+      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, patch, o, lane, rs_cur);
+      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, patch, o, lane, rs_cur);
       zero_half(0);
       zero_half(1);
       pp_barrier();
@@ -1475,12 +1477,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   }
   // The last tile's m1 half is still in the accumulators.  Every DMA of this workgroup must have landed before it
   // ends, and after that the half-tile buffers are dead: they serve as 8 private patches for the final stores.
-  if constexpr (!(F32OUT && STORES)) {
+  if constexpr (!(TEND && STORES)) {
     if (wr == 0) pp_barrier();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   pp_barrier();
-  if constexpr (F32OUT && STORES) {
+  if constexpr (TEND && STORES) {
     // (stored at the end of every tile)
   } else if constexpr (!STORES) {
     float keep = 0.f;
