@@ -989,7 +989,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   constexpr int PATCH = 4096;
   // TEND: the epilogue runs at the end of the tile, both wave groups in step (fp32 outputs).  ABL 7 = the same for bf16
   // outputs (microbench variant 27): 1 035 vs 1 105 TFLOP/s for the in-slot jobs on the encoder QKV shape, so bf16 stays in-slot
-  constexpr bool TEND = (EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD) || (ABL == 7 && (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU));
+  constexpr bool LSE = EPI == GRAM_EPI_F32_LSE;  // lm_head in sparse mode: only the (max, sum exp) partials leave the kernel
+  constexpr bool TEND = (EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD) || LSE || (ABL == 7 && (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU));
   constexpr int RS_OFF = 8 * HT + 4 * 4096;  // bf16 epilogues: 2 x 1 KiB of row scales behind the patches
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 8 half-tile buffers + epilogue patches (+ row scales)
   const int tid = threadIdx.x;
@@ -997,7 +998,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // tell hipcc it is wave-uniform: everything derived stays in SGPRs
   const int wr = wave >> 2, wc = wave & 3;
   const int r16 = lane & 15, g = lane >> 4;
-  const int ntn = KV ? N / TB / 2 : N / TB;  // KV: this launch walks every other block of inner/256 n-tiles
+  const int ntn = KV ? N / TB / 2 : (N + TB - 1) / TB;  // KV: every other block of inner/256 n-tiles; LSE: N may end in half a tile
   auto nt_of = [&](int ntl) {  // launch-local n-tile -> n-tile of the GEMM
     if constexpr (KV) {
       const int it = ep.inner >> 8, blk = (int)udiv_magic((uint32_t)ntl, (uint32_t)it, ep.mg_it);
@@ -1023,12 +1024,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   int c_tile = slot, c_kt = 0;
   // W offsets never change (H2 = H1 + 32 rows goes into the uniform base); A offsets change only for the M-tail tile
   const char *c_A, *c_W;
-  uint32_t offA[2][2], offW[2];
+  uint32_t offA[2][2], offW[2], offW2[LSE ? 2 : 1];  // LSE: W rows clamped per tile (the last n-tile may be half empty)
+  if constexpr (!LSE) {
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int r = (wave * 2 + p) * 8 + (lane >> 3);  // row of the half-tile image
-    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-    offW[p] = ((uint32_t)((r >> 5) * 64 + (r & 31)) * (uint32_t)K + chunk * 8) * 2u;
+    for (int p = 0; p < 2; ++p) {
+      const int r = (wave * 2 + p) * 8 + (lane >> 3);  // row of the half-tile image
+      const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+      offW[p] = ((uint32_t)((r >> 5) * 64 + (r & 31)) * (uint32_t)K + chunk * 8) * 2u;
+    }
   }
   auto set_offsets = [&]() {
     const int mt = c_tile / ntn, nt = nt_of(c_tile - mt * ntn);
@@ -1044,6 +1047,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       const int arow = (r >> 6) * 128 + (r & 63);  // + 64 for H3
       offA[0][p] = ((uint32_t)min(arow, mleft) * (uint32_t)lda + chunk * 8) * 2u;
       offA[1][p] = ((uint32_t)min(arow + 64, mleft) * (uint32_t)lda + chunk * 8) * 2u;
+      if constexpr (LSE) {
+        const int wleft = N - 1 - nt * TB, wrow = (r >> 5) * 64 + (r & 31);
+        offW[p] = ((uint32_t)min(wrow, wleft) * (uint32_t)K + chunk * 8) * 2u;
+        offW2[p] = ((uint32_t)min(wrow + 32, wleft) * (uint32_t)K + chunk * 8) * 2u;
+      }
     }
   };
   auto advance = [&]() {
@@ -1061,9 +1069,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
         dma16_asm(dst, offA[t == 3][0], base);
         dma16_asm(dst + 1024, offA[t == 3][1], base);
       } else {
-        const char* base = c_W + c_kt * (BK * 2) + (t == 2 ? (size_t)32 * K * 2 : 0);
-        dma16_asm(dst, offW[0], base);
-        dma16_asm(dst + 1024, offW[1], base);
+        if constexpr (LSE) {
+          const char* base = c_W + c_kt * (BK * 2);
+          dma16_asm(dst, t == 2 ? offW2[0] : offW[0], base);
+          dma16_asm(dst + 1024, t == 2 ? offW2[1] : offW[1], base);
+        } else {
+          const char* base = c_W + c_kt * (BK * 2) + (t == 2 ? (size_t)32 * K * 2 : 0);
+          dma16_asm(dst, offW[0], base);
+          dma16_asm(dst + 1024, offW[1], base);
+        }
       }
     }
   };
@@ -1458,11 +1472,38 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       // other persistent kernel): inside the slots its residual loads drain the in-order DMA queue four times per tile and
       // group; here once.  Group 0 waits for group 1's last MFMA slot, both store, and group 1 falls one barrier behind again.
       if (wr == 0) pp_barrier();
+      if constexpr (LSE) {
+        // per row and 64-column block (= this wave's columns) the pair (max, sum exp(x - max)), reduced in exactly the
+        // order of the 128-row kernels' epilogue, so a user's scores do not depend on which kernel its batch size selects
+        const int blk = (n0 + wc * 64) >> 6;
+        if (blk < ep.lse_nblk) {  // (the padding half of the last n-tile has no block)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) mx = fmaxf(mx, acc[i][j][e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sm += __expf(acc[i][j][e] - mx);
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            const int m = m0 + wr * 128 + j * 16 + r16;
+            if (g == 0 && m < M) *reinterpret_cast<float2*>(ep.lse_part + ((size_t)m * ep.lse_nblk + blk) * 2) = make_float2(mx, sm);
+          }
+        }
+      } else {
       const PPOut o = make_out(m0, n0);
       pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 0, patch, o, lane, rs_cur);
       pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 2, patch, o, lane, rs_cur);
       pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, patch, o, lane, rs_cur);
       pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, patch, o, lane, rs_cur);
+      }
       zero_half(0);
       zero_half(1);
       pp_barrier();
@@ -1518,12 +1559,11 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     return r ? r : launch_pp<PP_KV_V, ABL>(A, W, M, N, K, lda, ep, st);
   } else {
   constexpr int smem = 8 * 16384 + 8 * 4096;  // 160 KiB
-  if (N % 256 || (K / BK) % 2 || K / BK < 4 || (ep.ss_in && ep.ss_nblk != 0)) return GRAM_E_ARG;
+  if ((EPI == GRAM_EPI_F32_LSE ? N % 128 : N % 256) || (K / BK) % 2 || K / BK < 4 || (ep.ss_in && ep.ss_nblk != 0)) return GRAM_E_ARG;
+  if (EPI == GRAM_EPI_F32_LSE && ep.C) return GRAM_E_ARG;  // dense logits: the 128-row kernels
   if ((size_t)256 * lda * 2 >= (1ull << 31) || (size_t)256 * K * 2 >= (1ull << 31) || (size_t)256 * ep.ldc * 4 >= (1ull << 31))
     return GRAM_E_ARG;  // per-tile 32-bit offsets
-  if constexpr (EPI == GRAM_EPI_F32_LSE) {
-    return GRAM_E_ARG;
-  } else {
+  {
     if constexpr (EPI == PP_KV_K || EPI == PP_KV_V) {  // a tile inside one layer's K or V block, 32-row blocks inside one passage
       if (ep.inner % 256 || ((ep.pmap ? ep.pL : ep.S) % 32) || M % 32) return GRAM_E_ARG;
       if (ep.S > 4096 || (ep.pmap && (ep.pL > 4096 || ep.pN > 64 || (long)ep.B * ep.pN >= (1l << 26))) || M >= (1 << 30)) return GRAM_E_ARG;
@@ -1532,7 +1572,7 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
       ep.mg_pN = magic_u32(ep.pmap ? ep.pN : 1);
       ep.mg_it = magic_u32(ep.inner >> 8);
     }
-    const int ntiles = ((EPI == PP_KV_K || EPI == PP_KV_V) ? N / 512 : N / 256) * ((M + 255) / 256);
+    const int ntiles = ((EPI == PP_KV_K || EPI == PP_KV_V) ? N / 512 : (N + 255) / 256) * ((M + 255) / 256);
     static int n_cu = 0;
     if (n_cu == 0) {
       int dev = 0;
@@ -1596,7 +1636,12 @@ int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiAr
 template <int EPI>
 int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
   gram_prof::Scope prof(GRAM_K_GEMM, st, 2.0 * M * N * K);
-  if constexpr (EPI == GRAM_EPI_F32_LSE) {  // written for the 64-column wave tiles only
+  if constexpr (EPI == GRAM_EPI_F32_LSE) {  // 64-column wave tiles only: the ping-pong kernel (partials only) or the 128-row kernels
+    static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
+    if ((g_force_variant == V_PP || (g_force_variant < 0 && use_pp == 1 && M >= 32768)) && !ep.C) {
+      const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
+      if (r != GRAM_E_ARG) return r;
+    }
     return pick_variant(M, N, K) == V_DMA ? launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st)
                                           : launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, st);
   } else {

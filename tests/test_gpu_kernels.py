@@ -410,6 +410,30 @@ def test_lm_head_fused_lse(G, M, N, K):
     assert not torch.isnan(part).any()
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 32128, 768), (300, 384, 256), (256 * 3 + 40, 1024, 512)])
+def test_lm_head_lse_persistent(G, M, N, K):
+    """Sparse mode (logits never stored) on the ping-pong kernel: the (max, sum exp) partials are reduced in the same
+    order as in the 128-row kernels, so they are compared bit for bit; N = 32 128 ends in a half-empty 256-column tile."""
+    from gram_amd import _lib
+    L_ = G.lib()
+    A, W = G.bf(_r(M, K, seed=33, scale=2.0)), G.bf(_r(N, K, seed=34, scale=K ** -0.5))
+    parts = {}
+    try:
+        for v in (3, 22):
+            L_.gram_debug_set_gemm_variant(v)
+            part = torch.full((M, N // 64, 2), float("nan"), dtype=torch.float32, device=G.DEV)
+            _lib.check(L_.gram_gemm_bf16_lse(G.p(A), G.p(W), None, G.p(part), M, N, K, K, N, G.stream()), "gemm_lse")
+            torch.cuda.synchronize()
+            parts[v] = part
+    finally:
+        L_.gram_debug_set_gemm_variant(-1)
+    assert not torch.isnan(parts[22]).any()
+    assert torch.equal(parts[3], parts[22])
+    lse = torch.empty(M, dtype=torch.float32, device=G.DEV)
+    _lib.check(L_.gram_lse_combine(G.p(parts[22]), G.p(lse), M, N // 64, G.stream()), "lse_combine")
+    assert torch.allclose(lse, torch.logsumexp(A.float() @ W.float().T, -1), atol=2e-3, rtol=1e-5)
+
+
 def test_greedy_step_bit_exact_vs_oracle(G):
     """gram_greedy_step / gram_greedy_finalize on given logits == the oracle's restated HF greedy_search."""
     from gram_amd import _lib
