@@ -969,6 +969,73 @@ __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, c
   }
 }
 
+// Tile-end fp32 epilogue of the ping-pong kernel: the wave's 128 x 64 outputs in two halves of 64 rows.  The 16 residual
+// loads of a half (64 registers -- fragments and address registers of the k-loop are dead here) go out together, so a
+// tile exposes two HBM round trips instead of one per 16-row pass; the passes then run through the 4-KiB patch.
+template <int EPI>
+__device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patch, const PPOut& o, int lane_) {
+  int lane = lane_;
+  asm volatile("" : "+v"(lane));
+  const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 res[16];
+    if constexpr (EPI == GRAM_EPI_F32_ADD) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) res[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (o.rows > 0) {  // (wave-uniform; a wave whose first row is past M has nothing to load: o.c points past the matrix)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int mr = min(half * 64 + q * 4 + (lane >> 4), o.rows - 1);  // rows past M inside the block: clamped, never stored
+          res[q] = *reinterpret_cast<const f32x4*>(o.c + ((uint32_t)mr * o.ldc_b + (lane & 15) * 16));
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int j = half * 4 + p;
+      // 16 rows x 64 cols fp32: patch[16][256 B], chunk c (16 B) at c ^ row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(patch + r16 * 256 + (((i * 4 + g) ^ r16) * 16)) = acc[i][j];
+      __builtin_amdgcn_wave_barrier();
+      float ssq4[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 4 + (lane >> 4), c = lane & 15;
+        f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16));
+        const int mr = j * 16 + row;
+        float ssq = 0.f;
+        if (mr < o.rows) {
+          f32x4* pc = reinterpret_cast<f32x4*>(o.c + ((uint32_t)mr * o.ldc_b + c * 16));
+          if constexpr (EPI == GRAM_EPI_F32_ADD) val += res[p * 4 + it];
+          *pc = val;
+          if constexpr (EPI == GRAM_EPI_F32_ADD) {
+            if (o.xb) {
+              *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + c * 8)) = pack_bf16x4(val);
+              ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
+            }
+          }
+        }
+        ssq4[it] = ssq;
+      }
+      if constexpr (EPI == GRAM_EPI_F32_ADD) {
+        if (o.ss) {  // the 16 lanes of a row cover exactly one 64-column block; same butterfly as the other kernels
+#pragma unroll
+          for (int sh = 1; sh < 16; sh <<= 1)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) ssq4[it] += __shfl_xor(ssq4[it], sh, 64);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int mr = j * 16 + it * 4 + (lane >> 4);
+            if ((lane & 15) == 0 && mr < o.rows) o.ss[(uint32_t)mr * o.ss_nblk] = ssq4[it];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // full: all 128 rows of the wave exist (no per-row predicates: the stores of a pass issue back to back and
 // their number is exact, which the counted DMA waits of the following slots rely on)
 template <int EPI, int SMODE = 0>
@@ -1499,10 +1566,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
         }
       } else {
       const PPOut o = make_out(m0, n0);
-      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 0, patch, o, lane, rs_cur);
-      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 2, patch, o, lane, rs_cur);
-      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, patch, o, lane, rs_cur);
-      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, patch, o, lane, rs_cur);
+      if constexpr (F32OUT) {
+        pp_store_tile_f32<EPI>(acc, patch, o, lane);
+      } else {
+        pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 0, patch, o, lane, rs_cur);
+        pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 2, patch, o, lane, rs_cur);
+        pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, patch, o, lane, rs_cur);
+        pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, patch, o, lane, rs_cur);
+      }
       }
       zero_half(0);
       zero_half(1);
@@ -1645,6 +1716,13 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
     return pick_variant(M, N, K) == V_DMA ? launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st)
                                           : launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, st);
   } else {
+  if constexpr (EPI == GRAM_EPI_F32_ADD) {  // big-M residual GEMMs: the ping-pong kernel with its tile-end epilogue, whatever N and K
+    static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
+    if (g_force_variant < 0 && (use_pp == 1 || use_pp == 2) && M >= 32768) {
+      const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
+      if (r != GRAM_E_ARG) return r;
+    }
+  }
   switch (pick_variant(M, N, K)) {
     case V_DMA: return launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st);
     case V_DMA2: return launch_dma<EPI, 2, 2>(A, W, M, N, K, lda, ep, st);
@@ -1659,13 +1737,10 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
       static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
       if (use_pp && g_force_variant < 0 &&
           (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || (EPI == GRAM_EPI_KV_BANK && use_pp != 3) ||
-           (EPI == GRAM_EPI_F32_ADD && K >= 2048 && use_pp != 3 && use_pp != 4))) {
+           (EPI == GRAM_EPI_F32_ADD && use_pp != 3 && use_pp != 4))) {
         const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
         if (r != GRAM_E_ARG) return r;
       }
-      // short-K fp32-residual GEMMs are epilogue-bound: 4 workgroups per CU of the 128x128 kernel overlap one tile's
-      // read-modify-write with the others' MFMAs a little better than the persistent kernel (+3-5 % at K = 768)
-      if (EPI == GRAM_EPI_F32_ADD && K < 2048 && g_force_variant < 0) return launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st);
       return launch_il<EPI>(A, W, M, N, K, lda, ep, st);
     }
     case 9: case 10: case 11: case 12:  // ablations of the DMA-interleaved kernel (bf16 epilogue only; bench_gemm.py)
