@@ -46,7 +46,8 @@ class NormFusion(C.Structure):
 
 
 class Compaction(C.Structure):
-    _fields_ = [("n_active", i32), ("passage_map", vp), ("ids", vp), ("mask", vp)]
+    _fields_ = [("n_active", i32), ("passage_map", vp), ("ids", vp), ("mask", vp),
+                ("n_cached", i32), ("cache_L", i32), ("cache_x", vp), ("cache_slot", vp)]
 
 
 class ModelDesc(C.Structure):
@@ -100,6 +101,8 @@ SIGNATURES = {
     "gram_rmsnorm_bf16_map": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, f32, f32, vp, C.c_int, C.c_int, vp, vp]),
     "gram_generate_ex": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.POINTER(Trie),
                                    C.POINTER(Compaction), vp, i64, vp, vp, C.POINTER(i32), vp]),
+    "gram_encode_passages": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, i64, vp, vp]),
+    "gram_gather_passage_x": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "gram_generate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.POINTER(Trie),
                                 vp, i64, vp, vp, C.POINTER(i32), vp]),
 }
@@ -122,7 +125,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gram_abi_version() != 1:
+    if lib.gram_abi_version() != 2:
         raise ImportError("libgram_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -132,9 +132,8 @@ int check_shapes(const gram_model* m, int B, int N, int L, int K, int Tmax) {
     if (e__) return e__;  \
   } while (0)
 
-// ids/mask: [P][L] for the P passages the encoder runs on (all B*N, or the active ones with their flat indices in pmap)
-int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const uint8_t* mask, int B, int N, int L, int P,
-           const int32_t* pmap, void* st) {
+// The encoder layers on P passages (ids/mask [P][L]); leaves the residual stream in w.x rows [0, P*L).
+int encoder_layers(const gram_model* m, const Workspace& w, const int64_t* ids, const uint8_t* mask, int L, int P, void* st) {
   const gram_model_desc_t& c = m->d;
   const int d = c.d_model, inner = c.n_heads * 64, F = c.d_ff, H = c.n_heads;
   const int Me = P * L;
@@ -165,6 +164,25 @@ int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const ui
     TRY(gram_gemm_bf16(w.u, m->enc_wo2[i], w.x, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, st));
   }
   }
+  return 0;
+}
+
+struct CachedPassages {  // gram_compaction_t's cache fields
+  int n;
+  int cache_L;
+  const float* x;
+  const int32_t* slot;
+};
+
+// P passages (all B*N, or the active ones with their flat indices in pmap): the first P - cached.n go through the
+// encoder (ids/mask [P - cached.n][L]), the rest take their residual-stream rows from the passage cache.
+int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const uint8_t* mask, int B, int N, int L, int P,
+           const int32_t* pmap, const CachedPassages& cached, void* st) {
+  const gram_model_desc_t& c = m->d;
+  const int d = c.d_model, inner = c.n_heads * 64, H = c.n_heads;
+  const int Pe = P - cached.n, Me = P * L;
+  if (Pe > 0) TRY(encoder_layers(m, w, ids, mask, L, Pe, st));
+  if (cached.n > 0) TRY(gram_gather_passage_x(cached.x, cached.slot, w.x + (size_t)Pe * L * d, cached.n, L, cached.cache_L, d, st));
   // final norm + per-passage position embedding = the late fusion (gram.py:238-255); the
   // (B*N, L, d) -> (B, N*L, d) view is free: rows are already user-major.
   TRY(gram_rmsnorm_bf16_map(w.x, c.enc_final_ln, w.h, Me, d, c.eps, 1.f, c.use_position_embedding ? c.pos_emb_f32 : nullptr, N, L,
@@ -286,13 +304,25 @@ extern "C" int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids
   TRY(check_shapes(m, B, N, L, K, max_length));
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
-  TRY(encode(m, w, input_ids, mask, B, N, L, B * N, nullptr, stream));
+  TRY(encode(m, w, input_ids, mask, B, N, L, B * N, nullptr, CachedPassages{0, 0, nullptr, nullptr}, stream));
   if (enc_out_bf16) {
     hipError_t e = hipMemcpyAsync(enc_out_bf16, w.h, (size_t)B * N * L * m->d.d_model * sizeof(bf16), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
   return 0;
+}
+
+extern "C" int gram_encode_passages(const gram_model_t* m, const int64_t* ids, const uint8_t* mask, int P, int L, void* workspace,
+                                    int64_t workspace_bytes, float* x_out, void* stream) {
+  TRY(check_shapes(m, P, 1, L, 1, 2));
+  if (!ids || !mask || !x_out) return GRAM_E_ARG;
+  Workspace w = carve(m, workspace, P, 1, L, 1, 2);
+  if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
+  TRY(encoder_layers(m, w, ids, mask, L, P, stream));
+  hipError_t e = hipMemcpyAsync(x_out, w.x, (size_t)P * L * m->d.d_model * sizeof(float), hipMemcpyDeviceToDevice,
+                                (hipStream_t)stream);
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 extern "C" int gram_decode_step(const gram_model_t* m, const int32_t* tokens, const int32_t* anc, const uint8_t* mask, int B, int N,
@@ -317,16 +347,22 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
                                 const gram_compaction_t* comp, void* workspace, int64_t workspace_bytes, int64_t* sequences,
                                 float* scores, int32_t* width_host, void* stream) {
   TRY(check_shapes(m, B, N, L, K, max_length));
-  if (comp && (comp->n_active < B || comp->n_active > B * N || !comp->passage_map || !comp->ids || !comp->mask)) return GRAM_E_ARG;
+  if (comp) {
+    const int n_enc = comp->n_active - comp->n_cached;
+    if (comp->n_active < B || comp->n_active > B * N || !comp->passage_map || comp->n_cached < 0 || n_enc < 0) return GRAM_E_ARG;
+    if (n_enc > 0 && (!comp->ids || !comp->mask)) return GRAM_E_ARG;
+    if (comp->n_cached > 0 && (!comp->cache_x || !comp->cache_slot || comp->cache_L < 1)) return GRAM_E_ARG;
+  }
   if (!trie || nret < 1 || nret > K || !sequences || (!scores && K != 1)) return GRAM_E_ARG;
   if ((long long)K * trie->max_fanout > 16384) return GRAM_E_ARG;
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
   w.beam.length_penalty = length_penalty;
   if (comp)  // the encoder runs on the active passages only; padded ones leave their bank positions untouched (never read)
-    TRY(encode(m, w, comp->ids, comp->mask, B, N, L, comp->n_active, comp->passage_map, stream));
+    TRY(encode(m, w, comp->ids, comp->mask, B, N, L, comp->n_active, comp->passage_map,
+               CachedPassages{comp->n_cached, comp->cache_L, comp->cache_x, comp->cache_slot}, stream));
   else
-    TRY(encode(m, w, input_ids, mask, B, N, L, B * N, nullptr, stream));
+    TRY(encode(m, w, input_ids, mask, B, N, L, B * N, nullptr, CachedPassages{0, 0, nullptr, nullptr}, stream));
   TRY(gram_beam_init(&w.beam, trie, /*decoder_start_token_id=*/0, stream));
   if (K == 1) {  // HF: num_beams == 1 -> greedy_search (raw logits, no hypotheses, no scores)
     for (int t = 0; t + 1 < max_length; ++t) {

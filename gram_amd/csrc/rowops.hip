@@ -172,6 +172,19 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restric
   if ((a.x ^ a.y ^ a.z ^ a.w) == 0x9e3779b9u && sink) *sink = a.x;  // keeps the loads alive; practically never taken
 }
 
+// passage cache -> residual stream: one 16-byte chunk per thread, consecutive threads on consecutive chunks of a row
+__global__ __launch_bounds__(256) void gather_passage_x_kernel(const float* __restrict__ cache, const int32_t* __restrict__ slot,
+                                                               float* __restrict__ x, int64_t nchunks, int L, int cache_L, int d4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  const int c = (int)(i % d4);
+  const int64_t row = i / d4;
+  const int l = (int)(row % L);
+  const int64_t p = row / L;
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (l < cache_L) v = reinterpret_cast<const f32x4*>(cache)[((int64_t)slot[p] * cache_L + l) * d4 + c];
+  reinterpret_cast<f32x4*>(x)[i] = v;
+}
 }  // namespace
 
 extern "C" int gram_debug_stream_read(const void* src, size_t bytes, void* sink, void* stream) {
@@ -247,6 +260,18 @@ extern "C" int gram_row_lse(const float* logits, float* lse, int R, int V, void*
   if (R < 1 || (V & 3)) return GRAM_E_ARG;
   gram_prof::Scope prof(GRAM_K_LSE, (hipStream_t)stream, 4.0 * R * V);
   hipLaunchKernelGGL(row_lse_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, lse, V);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gram_gather_passage_x(const float* cache_x, const int32_t* slot, float* x, int n, int L, int cache_L, int d,
+                                     void* stream) {
+  if (!cache_x || !slot || !x || n < 1 || L < 1 || cache_L < 1 || d < 4 || (d & 3)) return GRAM_E_ARG;
+  const int64_t nchunks = (int64_t)n * L * (d / 4);
+  if ((nchunks + 255) / 256 > 0x7fffffffLL) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, 8.0 * n * L * d);
+  hipLaunchKernelGGL(gather_passage_x_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cache_x,
+                     slot, x, nchunks, L, cache_L, d / 4);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

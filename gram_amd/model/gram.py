@@ -131,6 +131,7 @@ class GRAM(nn.Module):
         self._version = 0
         self._workspace = None
         self._tries: Dict[int, FlatTrie] = {}
+        self._pcache = None  # passage cache: dict(x, canon, keys, perm) on the device
 
     # ------------------------------------------------------------------ weights
     def _init_weights(self) -> None:
@@ -174,6 +175,7 @@ class GRAM(nn.Module):
 
     def _invalidate(self) -> None:
         self._version += 1
+        self._pcache = None  # cached encoder states belong to the old weights
 
     def _apply(self, fn, *a, **kw):  # .to()/.cuda()/.float() all funnel through here
         out = super()._apply(fn, *a, **kw)
@@ -328,6 +330,119 @@ class GRAM(nn.Module):
             self._tries = {key: cached}  # one live Trie per eval; drop stale ones
         return cached
 
+    # ------------------------------------------------------------------ which passages the encoder runs on
+    _CACHE_L = _lib.GRAM_MAX_PASSAGE_LEN
+
+    @staticmethod
+    def _canonical(rows_ids: torch.Tensor, rows_mask: torch.Tensor) -> torch.Tensor:
+        """(P, 128) int32: token id where valid, -1 elsewhere -- the identity of a passage (position-wise)."""
+        canon = torch.where(rows_mask.bool(), rows_ids, rows_ids.new_full((), -1)).to(torch.int32)
+        return torch.nn.functional.pad(canon, (0, GRAM._CACHE_L - canon.shape[1]), value=-1)
+
+    @staticmethod
+    def _passage_keys(canon: torch.Tensor) -> torch.Tensor:
+        # 64-bit key, overflow-free ((id+1) < 2^15, multiplier < 2^31, 128 terms); a key match is always
+        # confirmed against the stored tokens, so a collision costs a miss, never a wrong hit
+        g = torch.Generator().manual_seed(0x6772616D)
+        mult = torch.randint(1, 2 ** 31 - 1, (GRAM._CACHE_L,), generator=g, dtype=torch.int64).to(canon.device)
+        return ((canon.to(torch.int64) + 1) * mult).sum(dim=1)
+
+    @torch.no_grad()
+    def cache_passages(self, input_ids, attention_mask, chunk: int = 1024) -> int:
+        """Pre-encode user-independent passages.
+
+        A GRAM input is passage 0 = the user prompt plus up to ``max_item_num`` ITEM prompts
+        (test_dataset_gram.py:115-123,203-210); EncoderWrapper.forward (gram.py:200-256) encodes every passage on
+        its own and adds the slot's position embedding afterwards, so an item prompt's encoder states are the same
+        for every user and every slot.  Passages registered here (``(P, L)`` or ``(B, N, L)`` ids + mask, e.g. all
+        item prompts of the dataset) are encoded once; ``generate`` then recognises them by their tokens and runs the
+        encoder only on the rest.  Results are bit-identical with and without the cache.  The cache holds the fp32
+        residual stream (128 x d_model x 4 B per passage) on the device and is dropped whenever the weights change.
+        Returns the number of passages cached so far."""
+        handle = self._pack()
+        lib = _lib.load()
+        dev = self._device()
+        ids = input_ids.to(dev, torch.int64).reshape(-1, input_ids.shape[-1])
+        mask = attention_mask.to(dev).reshape(-1, attention_mask.shape[-1]).ne(0)
+        if ids.shape != mask.shape or ids.shape[1] > self._CACHE_L:
+            raise ValueError(f"passages must be (P, L <= {self._CACHE_L}) ids with a mask of the same shape")
+        keep = mask.any(dim=1)
+        canon = self._canonical(ids[keep], mask[keep])
+        keys = self._passage_keys(canon)
+        # drop duplicates inside the call and passages already cached
+        order = torch.argsort(keys, stable=True)
+        first = torch.ones_like(keys, dtype=torch.bool)
+        first[order[1:]] = keys[order[1:]] != keys[order[:-1]]
+        if self._pcache is not None:
+            first &= self._lookup(canon, keys)[0].logical_not()
+        canon = canon[first]
+        if canon.shape[0] == 0:
+            return 0 if self._pcache is None else int(self._pcache["canon"].shape[0])
+        d = self.config.d_model
+        full_ids = canon.clamp(min=0).to(torch.int64).contiguous()
+        full_mask = canon.ge(0).view(torch.uint8).contiguous()
+        x = torch.empty(canon.shape[0], self._CACHE_L, d, dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            for lo in range(0, canon.shape[0], chunk):
+                n = min(chunk, canon.shape[0] - lo)
+                ws = self._get_workspace(handle, n, 1, self._CACHE_L, 1, 2)
+                _lib.check(lib.gram_encode_passages(handle, full_ids[lo:lo + n].data_ptr(), full_mask[lo:lo + n].data_ptr(), n,
+                                                    self._CACHE_L, ws.data_ptr(), ws.numel(), x[lo:lo + n].data_ptr(), stream),
+                           "gram_encode_passages")
+        if self._pcache is not None:
+            x = torch.cat([self._pcache["x"], x], 0)
+            canon = torch.cat([self._pcache["canon"], canon], 0)
+        keys = self._passage_keys(canon)
+        skeys, perm = torch.sort(keys, stable=True)
+        self._pcache = dict(x=x.contiguous(), canon=canon.contiguous(), keys=skeys, perm=perm)
+        return int(canon.shape[0])
+
+    def clear_passage_cache(self) -> None:
+        self._pcache = None
+
+    def _lookup(self, canon: torch.Tensor, keys: torch.Tensor):
+        pc = self._pcache
+        pos = torch.searchsorted(pc["keys"], keys).clamp(max=pc["keys"].numel() - 1)
+        slot = pc["perm"][pos]
+        hit = (pc["keys"][pos] == keys) & (pc["canon"].index_select(0, slot) == canon).all(dim=1)
+        return hit, slot
+
+    def _plan_encoder(self, ids, mask, B, N, Lp):
+        """gram_compaction_t for this batch, or None when the encoder simply runs on all B*N passages.
+
+        Ragged batches: the Collator pads every user to the batch's largest passage count with fully masked passages
+        (Collator.py:410-436); the encoder skips them.  Passages found in the passage cache skip it too.  One small
+        D2H sync for the counts; the gathers are input plumbing.  GRAM_COMPACT=0 disables both."""
+        if os.environ.get("GRAM_COMPACT", "1") == "0" or (N == 1 and self._pcache is None):
+            return None
+        rows_ids, rows_mask = ids.view(B * N, Lp), mask.view(B * N, Lp)
+        active = rows_mask.ne(0).any(dim=1)
+        if self._pcache is not None:
+            canon = self._canonical(rows_ids, rows_mask)
+            hit, slot = self._lookup(canon, self._passage_keys(canon))
+            hit &= active
+        else:
+            hit = torch.zeros_like(active)
+        miss = active & ~hit
+        n_miss, n_hit, users = torch.stack([miss.sum(), hit.sum(), active.view(B, N).any(dim=1).sum()]).tolist()
+        if users < B:
+            raise ValueError("every user needs at least one passage with a valid token")
+        if n_hit == 0 and n_miss == B * N:
+            return None
+        midx, hidx = miss.nonzero().squeeze(1), hit.nonzero().squeeze(1)
+        c_ids = rows_ids.index_select(0, midx).contiguous()
+        c_mask = rows_mask.index_select(0, midx).contiguous()
+        c_map = torch.cat([midx, hidx]).to(torch.int32).contiguous()
+        keep = [c_ids, c_mask, c_map]
+        comp = _lib.Compaction(n_miss + n_hit, c_map.data_ptr(), c_ids.data_ptr(), c_mask.data_ptr(), 0, 0, None, None)
+        if n_hit:
+            slots = slot.index_select(0, hidx).to(torch.int32).contiguous()
+            keep += [slots, self._pcache["x"]]
+            comp.n_cached, comp.cache_L = n_hit, self._CACHE_L
+            comp.cache_x, comp.cache_slot = self._pcache["x"].data_ptr(), slots.data_ptr()
+        return comp, keep
+
     # ------------------------------------------------------------------ the hot path
     @torch.no_grad()
     def generate(self, input_ids, attention_mask, max_length, prefix_allowed_tokens_fn=None, num_beams=1,
@@ -360,21 +475,7 @@ class GRAM(nn.Module):
                 raise NotImplementedError("greedy search needs the Trie closure form of prefix_allowed_tokens_fn")
             return self._generate_with_callback(ids, mask, B, N, Lp, K, nret, int(max_length), float(length_penalty),
                                                 prefix_allowed_tokens_fn, return_dict_in_generate)
-        # Ragged batches: the Collator pads every user to the batch's largest passage count with fully masked
-        # passages; gather the active ones so the encoder skips the rest (one 1-element D2H sync; the gathers are
-        # input plumbing).  GRAM_COMPACT=0 disables it.
-        comp = None
-        if os.environ.get("GRAM_COMPACT", "1") != "0" and N > 1:
-            active = mask.view(B * N, Lp).any(dim=1)
-            n_active = int(active.sum())
-            if n_active < B * N:
-                if int(active.view(B, N).any(dim=1).sum()) < B:
-                    raise ValueError("every user needs at least one passage with a valid token")
-                pidx = active.nonzero().squeeze(1)
-                c_ids = ids.view(B * N, Lp).index_select(0, pidx).contiguous()
-                c_mask = mask.view(B * N, Lp).index_select(0, pidx).contiguous()
-                c_map = pidx.to(torch.int32).contiguous()
-                comp = (_lib.Compaction(n_active, c_map.data_ptr(), c_ids.data_ptr(), c_mask.data_ptr()), (c_ids, c_mask, c_map))
+        comp = self._plan_encoder(ids, mask, B, N, Lp)
         flat = self._flat_trie(prefix_allowed_tokens_fn)
         ctrie, _keep = flat.to_device(dev)
         ws = self._get_workspace(handle, B, N, Lp, K, int(max_length))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GRAM_ABI_VERSION 1
+#define GRAM_ABI_VERSION 2
 
 #define GRAM_E_ARG (-1)       /* bad shape / unsupported size                           */
 #define GRAM_E_WORKSPACE (-2) /* workspace too small (see gram_workspace_bytes)          */
@@ -280,13 +280,33 @@ int gram_generate(const gram_model_t* m, const int64_t* input_ids, const uint8_t
 typedef struct {
   int32_t n_active;
   const int32_t* passage_map; /* device, i32 [n_active] */
-  const int64_t* ids;         /* device, i64 [n_active][L] */
-  const uint8_t* mask;        /* device, u8  [n_active][L] */
+  const int64_t* ids;         /* device, i64 [n_active - n_cached][L] */
+  const uint8_t* mask;        /* device, u8  [n_active - n_cached][L] */
+  /* Passage cache (all zero = off).  An item passage's encoder output depends neither on the
+   * user nor on the slot it sits in: EncoderWrapper runs every passage on its own and adds the slot's position
+   * embedding afterwards (gram.py:238-255).  The LAST n_cached entries of passage_map skip the encoder: their
+   * residual-stream rows (gram_encode_passages) are gathered from cache_x[cache_slot[i]] instead; rows at
+   * positions >= cache_L are zero-filled (they are padding, masked in the cross-attention).  passage_map need
+   * not be ascending.  Results are bit-identical to encoding the passages in place. */
+  int32_t n_cached;
+  int32_t cache_L;            /* rows per cached passage */
+  const float* cache_x;       /* device, f32 [slots][cache_L][d_model] */
+  const int32_t* cache_slot;  /* device, i32 [n_cached] */
 } gram_compaction_t;
 int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L,
                      int K, int nret, int max_length, float length_penalty, const gram_trie_t* trie_host,
                      const gram_compaction_t* compaction_host, void* workspace, int64_t workspace_bytes,
                      int64_t* sequences, float* scores, int32_t* width_host, void* stream);
+
+/* The encoder layers alone on P independent passages (T5Stack encoder role, gram_t5_modeling.py:1037-1296, up to
+ * but excluding final_layer_norm): x_out f32 [P][L][d_model] is the residual stream the final norm, the position
+ * embedding and the bank projection consume.  ids i64 [P][L], mask u8 [P][L].  Workspace as for
+ * gram_workspace_bytes(m, P, 1, L, 1, 2).  Feeds gram_compaction_t.cache_x. */
+int gram_encode_passages(const gram_model_t* m, const int64_t* ids, const uint8_t* mask, int P, int L,
+                         void* workspace, int64_t workspace_bytes, float* x_out, void* stream);
+/* x[i][l][:] = l < cache_L ? cache_x[slot[i]][l][:] : 0 for i < n, l < L (d % 4 == 0). */
+int gram_gather_passage_x(const float* cache_x, const int32_t* slot, float* x, int n, int L, int cache_L, int d,
+                          void* stream);
 
 /* ---- live per-kernel timing (bench.py) ------------------------------------------------ */
 enum gram_kernel_kind {

@@ -176,6 +176,51 @@ def test_passage_compaction_is_result_neutral(gpu, monkeypatch):
     assert torch.isfinite(comp["sequences_scores"]).all()
 
 
+@pytest.mark.parametrize("backbone,N,L,K", [("small", 5, 64, 8), ("t5-base", 4, 96, 20)])
+def test_passage_cache_is_result_neutral(gpu, backbone, N, L, K):
+    """SURVEY.md §8f N2: item passages drawn from a pool and registered with ``cache_passages`` skip the encoder;
+    sequences and scores are bit-identical to encoding everything in place -- with a ragged batch (fully padded
+    passages), items at different slots for different users, a cache encoded at L = 128 serving a batch trimmed to
+    L < 128, items that are NOT in the cache, and a workspace poisoned with NaN patterns between the runs."""
+    oc, sd, m = _model(gpu, backbone, 7)
+    cands = _trie_cands("Toys")
+    g = torch.Generator().manual_seed(33)
+    B, pool = 10, 7
+    p_ids, p_mask = _realistic_inputs(g, pool, 1, L)
+    p_ids, p_mask = p_ids[:, 0], p_mask[:, 0]
+    ids, mask = _realistic_inputs(g, B, N, L)  # passage 0 (user prompt) and the padding pattern stay as drawn
+    for b in range(B):
+        for n in range(1, N):
+            if mask[b, n].any() and (b + n) % 4 != 0:  # a quarter of the item slots keep passages unknown to the cache
+                j = int(torch.randint(0, pool, (1,), generator=g))
+                ids[b, n], mask[b, n] = p_ids[j], p_mask[j]
+    m.clear_passage_cache()
+    plain = _generate(m, ids, mask, cands, K)
+    p_seq, p_sc = plain["sequences"].cpu(), plain["sequences_scores"].cpu()
+    assert m.cache_passages(p_ids[:4], p_mask[:4]) == 4
+    assert m.cache_passages(torch.nn.functional.pad(p_ids[2:], (0, 128 - L)), torch.nn.functional.pad(p_mask[2:], (0, 128 - L))) == pool
+    assert m.cache_passages(p_ids, p_mask) == pool  # nothing new
+    m._workspace.fill_(0xFF)
+    plan = m._plan_encoder(ids.to(DEV), mask.to(DEV).view(torch.uint8), B, N, L)
+    assert plan is not None and 0 < plan[0].n_cached < plan[0].n_active <= B * N
+    n_pool_slots = sum(int(any(torch.equal(ids[b, n][mask[b, n]], p_ids[j][p_mask[j]]) for j in range(pool)))
+                       for b in range(B) for n in range(N) if mask[b, n].any())
+    assert plan[0].n_cached == n_pool_slots
+    cached = _generate(m, ids, mask, cands, K)
+    assert torch.equal(cached["sequences"].cpu(), p_seq)
+    assert torch.equal(cached["sequences_scores"].cpu(), p_sc)
+    # every passage cached (user prompts too): the encoder does not run at all
+    m.cache_passages(ids, mask)
+    plan = m._plan_encoder(ids.to(DEV), mask.to(DEV).view(torch.uint8), B, N, L)
+    assert plan[0].n_cached == plan[0].n_active
+    m._workspace.fill_(0xFF)
+    allc = _generate(m, ids, mask, cands, K)
+    assert torch.equal(allc["sequences"].cpu(), p_seq) and torch.equal(allc["sequences_scores"].cpu(), p_sc)
+    # new weights drop the cache
+    m.load_state_dict(m.state_dict())
+    assert m._pcache is None
+
+
 def test_runner_end_to_end_with_collator(gpu, tmp_path):
     """The drop-in flow of single_runner_gram.py:570-719 on the GPU path: texts -> CollatorGRAM (stub tokenizer) ->
     DataLoader -> get_runner("single").test_dataset_task -> Trie from the candidate strings, generate, decode, metrics,
