@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--ragged", action="store_true",
                     help="realistic batch: passage counts drawn from the dataset's histogram (padded to --passages), valid "
                          "lengths U[32, L]; not the headline configuration")
+    ap.add_argument("--item-pool", type=int, default=0,
+                    help="passages 1..N-1 of every user are drawn from a pool of this many item prompts, registered with "
+                         "GRAM.cache_passages before the warmup (SURVEY.md §8f N2); not the headline configuration")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL on ROCm)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: all ranks use cuda:0 (with --backend gloo; RCCL needs one GPU per rank)")
@@ -116,7 +119,31 @@ def main():
         lens = torch.randint(32, L + 1, (B, N), generator=g)
         mask = (torch.arange(L)[None, None, :] < lens[:, :, None]) & (torch.arange(N)[None, :, None] < n_user[:, None, None])
         ids[~mask] = 0
+    item_cache = None
+    if args.item_pool and N > 1:
+        pg = torch.Generator().manual_seed(77)  # the same pool on every rank
+        P = args.item_pool
+        pool_ids = torch.randint(2, 32100, (P, L), generator=pg)
+        pool_len = torch.randint(32, L + 1, (P,), generator=pg) if args.ragged else torch.full((P,), L)
+        pool_mask = torch.arange(L)[None, :] < pool_len[:, None]
+        pool_ids[torch.arange(P), pool_len - 1] = 1
+        pool_ids[~pool_mask] = 0
+        pick = torch.randint(0, P, (B, N - 1), generator=g)
+        slot_on = mask[:, 1:].any(-1)
+        ids[:, 1:] = pool_ids[pick]
+        mask[:, 1:] = pool_mask[pick] & slot_on[..., None]
+        ids[~mask] = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_cached = model.cache_passages(pool_ids.to(dev), pool_mask.to(dev))
+        torch.cuda.synchronize()
+        item_cache = {"pool": P, "cached_passages": n_cached, "prefill_s": round(time.perf_counter() - t0, 3),
+                      "cache_GiB": round(n_cached * 128 * cfg.d_model * 4 / 2 ** 30, 3)}
     ids_d, mask_d = ids.to(dev), mask.to(dev)
+    if item_cache is not None:
+        plan = model._plan_encoder(ids_d, mask_d.view(torch.uint8), B, N, L)
+        item_cache["passages_from_cache_per_step"] = int(plan[0].n_cached)
+        item_cache["passages_encoded_per_step"] = int(plan[0].n_active - plan[0].n_cached)
 
     def step():
         return model.generate(input_ids=ids_d, attention_mask=mask_d, max_length=max_length, prefix_allowed_tokens_fn=fn,
@@ -176,8 +203,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.dataset} Trie ({len(cands)} items, T={max_length - 1}), {args.backbone}, "
-                        f"{N} granularity passages x {L} tokens (S={N * L}), beam={K} top-{K}",
-            "ragged": bool(args.ragged), "users_per_step_per_gpu": B, "parallelism": f"dp{world} (users sharded, no data-path collective)",
+                        f"{N} granularity passages x {L} tokens (S={N * L}), beam={K} top-{K}"
+                        + (f"; item passages drawn from {args.item_pool} prompts and served by the passage cache "
+                           f"(NOT the headline configuration)" if item_cache else ""),
+            "ragged": bool(args.ragged), "item_cache": item_cache, "users_per_step_per_gpu": B, "parallelism": f"dp{world} (users sharded, no data-path collective)",
             "precision": "bf16 operands / fp32 accumulate, fp32 residual stream, softmax and scores",
         },
         "output_check": {"sequences_shape": list(out["sequences"].shape),
@@ -224,7 +253,7 @@ def main():
         try:
             pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1]))) if pmc_files else None
-            if pmc and pmc.get("batch") == B and args.backbone == "t5-base" and (N, L, K) == (3, 128, 20):
+            if pmc and not item_cache and not args.ragged and pmc.get("batch") == B and args.backbone == "t5-base" and (N, L, K) == (3, 128, 20):
                 roof_xa["traffic"] = pmc["cross_attn_kernel"]["hbm_bytes_per_launch"]
                 roof_xa["traffic_source"] = "profiles/" + pmc_files[-1]
                 roof_gemm["traffic"] = pmc["gemm_all"]["hbm_bytes_per_launch_avg"]

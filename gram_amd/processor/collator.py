@@ -88,6 +88,19 @@ class CollatorGRAM:
         width = int(mask.sum(-1).max())  # trim to the longest valid passage of the batch
         return ids[:, :, :width], mask[:, :, :width].bool()
 
+    def encode_passages(self, texts: Sequence[str]):
+        """Token ids / masks (P, L) of stand-alone passages, tokenised exactly as `_passages` tokenises them inside a
+        user's stack (each row on its own).  Used to register the dataset's item prompts (`item2input`,
+        test_dataset_gram.py:115-123) with `GRAM.cache_passages`."""
+        L = self.item_prompt_max_len
+        split = self.item_id_type == "split"
+        enc = self.tokenizer.batch_encode_plus(list(texts), max_length=999 if split else L, pad_to_max_length=True,
+                                               return_tensors="pt", truncation=True)
+        ids, mask = enc["input_ids"], enc["attention_mask"]
+        if split:
+            ids, mask = _strip_rows(ids, mask, L)
+        return ids, mask.bool()
+
     def __call__(self, batch: List[Dict]):
         target_ids, target_masks = self._targets([x["output"] for x in batch])
         item_text_ids, item_text_masks = self._passages([x["input"] for x in batch])

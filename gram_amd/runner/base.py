@@ -79,8 +79,28 @@ class BaseRunner:
     def _generate_model(self):
         return self.model_rec.module if hasattr(self.model_rec, "module") else self.model_rec
 
+    def _warm_passage_cache(self, testloader, chunk: int = 2048) -> int:
+        """Register the dataset's item prompts with the model's passage cache: every user's passages
+        1..h are `item2input[item]` texts (test_dataset_gram.py:115-123,203-210), the same for all users, so their
+        encoder states are computed once per eval instead of once per occurrence.  Needs a dataset exposing
+        `item2input` and a collate_fn with `encode_passages` (gram_amd.processor.CollatorGRAM); `--passage_cache 0`
+        turns it off.  Results do not change (bit-identical, tests/test_gpu_configs.py)."""
+        item2input = getattr(testloader.dataset, "item2input", None)
+        encode = getattr(getattr(testloader, "collate_fn", None), "encode_passages", None)
+        model = self._generate_model()
+        if not item2input or encode is None or not hasattr(model, "cache_passages") or not int(_arg(self.args, "passage_cache", 1)):
+            return 0
+        texts = sorted(set(item2input.values()))
+        start, n = time(), 0
+        for lo in range(0, len(texts), chunk):
+            ids, mask = encode(texts[lo:lo + chunk])
+            n = model.cache_passages(ids, mask)
+        logging.info(f"passage cache: {n} item prompts encoded in {time() - start:.2f}s")
+        return n
+
     def _score_loader(self, testloader):
         """Per-user hit ranks for one loader: (ranks int16 [n], total generate() seconds, examples)."""
+        self._warm_passage_cache(testloader)
         candidates = testloader.dataset.all_items
         encoded = self.encode_candidates(candidates)
         trie = gt.Trie(encoded)

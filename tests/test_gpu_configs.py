@@ -279,3 +279,19 @@ def test_runner_end_to_end_with_collator(gpu, tmp_path):
             agree += int(t == rows[n][-2].split("||")[0])
             n += 1
     assert agree >= n - 1, (agree, n)
+    # the same eval with the dataset's item prompts registered in the passage cache: identical TSV
+    class CachedUserSet(UserSet):
+        item2input = {f"I{j}": t for j, t in enumerate(sorted({h for u in users for h in u["input"][1:]}))}
+
+    args.pred_path = str(tmp_path / "preds_cached.tsv")
+    m.clear_passage_cache()
+    loader2 = DataLoader(CachedUserSet(users), batch_size=3, shuffle=False, collate_fn=CollatorGRAM(tok, args, mode="test"))
+    runner.test_dataset_task(loader2)
+    assert m._pcache is not None and m._pcache["canon"].shape[0] == len(CachedUserSet.item2input)
+    plan = None
+    for batch in loader2:
+        plan = m._plan_encoder(batch["item_text_ids"].to(DEV), batch["item_text_masks"].to(DEV).view(torch.uint8),
+                               *batch["item_text_ids"].shape)
+        assert plan[0].n_cached == int(batch["item_text_masks"][:, 1:].any(-1).sum())  # every item passage is a hit
+    assert open(args.pred_path).read() == open(str(tmp_path / "preds.tsv")).read()
+    m.clear_passage_cache()

@@ -141,6 +141,14 @@ def test_collator_matches_reference_fixtures(golden_dir):
         assert out["target_ids"].tolist() == c["target_ids"]
         assert out["target_masks"].long().tolist() == c["target_masks"]
         assert out["user_ids"] == c["user_ids"] and out["neg_item_ids"] is None
+        # stand-alone tokenisation of the same passages (what the passage cache is filled with) = the stacked rows
+        col = CollatorGRAM(StubTokenizer(), SimpleNamespace(**c["args"]), mode="test")
+        W = out["item_text_ids"].shape[-1]
+        for b, x in enumerate(c["batch"]):
+            p_ids, p_mask = col.encode_passages(x["input"])
+            n = len(x["input"])
+            assert torch.equal((p_ids * p_mask)[:, :W], out["item_text_ids"][b, :n] * out["item_text_masks"][b, :n])
+            assert torch.equal(p_mask[:, :W], out["item_text_masks"][b, :n]) and not p_mask[:, W:].any()
     # the reference cannot stack a user with more passages than slots (it raises inside torch.cat); the mirror says why
     args = SimpleNamespace(item_prompt_max_len=16, target_max_len=8, max_his=1, item_id_type="split", hierarchical_id_type="none")
     with pytest.raises(ValueError):
