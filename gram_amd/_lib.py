@@ -32,7 +32,11 @@ class KVBank(C.Structure):
 
 class Trie(C.Structure):
     _fields_ = [("child_off", vp), ("child_tok", vp), ("child_node", vp), ("n_nodes", i32), ("n_edges", i32),
-                ("max_fanout", i32)]
+                ("max_fanout", i32), ("min_seq_len", i32)]
+
+
+class LiveRows(C.Structure):
+    _fields_ = [("rows", vp), ("rowpos", vp), ("users", vp), ("tokens", vp), ("counts", vp)]
 
 
 class BeamState(C.Structure):
@@ -103,6 +107,10 @@ SIGNATURES = {
                                    C.POINTER(Compaction), vp, i64, vp, vp, C.POINTER(i32), vp]),
     "gram_encode_passages": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, i64, vp, vp]),
     "gram_gather_passage_x": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "gram_live_rows": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), C.POINTER(LiveRows), vp]),
+    "gram_dec_self_attn_live": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "gram_cross_attn_decode_live": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "gram_beam_step_sparse_live": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]),
     "gram_generate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.POINTER(Trie),
                                 vp, i64, vp, vp, C.POINTER(i32), vp]),
 }

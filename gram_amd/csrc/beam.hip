@@ -107,7 +107,8 @@ __global__ void beam_init_kernel(gram_beam_state_t st, gram_trie_t tr, int start
 
 __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gram_trie_t tr, const float* __restrict__ logits,
                                                         const float* __restrict__ lse, int V, int cur_len, int nc_max, int rows_per_user,
-                                                        const bf16* __restrict__ hd, const bf16* __restrict__ emb, int d) {
+                                                        const bf16* __restrict__ hd, const bf16* __restrict__ emb, int d,
+                                                        const int32_t* __restrict__ rowpos) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [nc_max]
   float* s_log = reinterpret_cast<float*>(keys + nc_max);                   // [nc_max / K] shared step-0 logits
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
       if (act) {
         if (!shared0) {
           while (s_pre[k + 1] <= ci) ++k;
-          lr = row0 + k;
+          lr = rowpos ? rowpos[row0 + k] : row0 + k;  // live-row step: hidden/lse are indexed by compact row
         }
         tok = tr.child_tok[tr.child_off[st.node[row0 + k]] + (ci - s_pre[k])];
       }
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
         if (shared0) {
           s_log[ci] = acc;
         } else {
-          const float sc = (acc - lse[lr]) + st.beam_scores[lr];
+          const float sc = (acc - lse[lr]) + st.beam_scores[row0 + k];
           keys[ci] = ((unsigned long long)f2ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(k * V + tok));
         }
       }
@@ -333,6 +334,66 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
   }
 }
 
+// Live rows of the coming decode step: a beam that left the Trie (its hypothesis went to the heap at EOS and HF refilled
+// the slot with a -inf candidate) or belongs to a finished user can only produce -inf candidates, so its decoder row is
+// never read by beam_step_kernel.  One workgroup compacts the others (ascending, i.e. grouped by user).
+__global__ __launch_bounds__(1024) void live_rows_kernel(gram_beam_state_t st, gram_trie_t tr, gram_live_rows_t out) {
+  __shared__ int s_w[16], s_tot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = st.K, B = st.B, R = B * K;
+  auto scan = [&](int v) {  // inclusive block scan of a 0/1 flag; returns the inclusive prefix, s_tot = block total
+    for (int o = 1; o < 64; o <<= 1) {
+      const int n = __shfl_up(v, o, 64);
+      if (lane >= o) v += n;
+    }
+    __syncthreads();  // previous round's s_w / s_tot readers are done
+    if (lane == 63) s_w[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      for (int w = 0; w < 16; ++w) {
+        const int t = s_w[w];
+        s_w[w] = acc;
+        acc += t;
+      }
+      s_tot = acc;
+    }
+    __syncthreads();
+    return v + s_w[wave];
+  };
+  int base = 0;
+  for (int c0 = 0; c0 < R; c0 += 1024) {
+    const int r = c0 + tid;
+    int live = 0;
+    if (r < R && !st.done[r / K]) {
+      const int nd = st.node[r];
+      live = nd >= 0 && tr.child_off[nd + 1] > tr.child_off[nd];
+    }
+    const int pos = base + scan(live) - 1;
+    if (live) {
+      out.rows[pos] = r;
+      out.tokens[pos] = st.tokens[r];
+    }
+    if (r < R) out.rowpos[r] = live ? pos : -1;
+    base += s_tot;
+  }
+  __syncthreads();  // rowpos written by this workgroup is visible to it
+  int ubase = 0;
+  for (int c0 = 0; c0 < B; c0 += 1024) {
+    const int b = c0 + tid;
+    int live = 0;
+    if (b < B)
+      for (int k = 0; k < K; ++k) live |= out.rowpos[b * K + k] >= 0;
+    const int pos = ubase + scan(live) - 1;
+    if (live) out.users[pos] = b;
+    ubase += s_tot;
+  }
+  if (tid == 0) {
+    out.counts[0] = base;
+    out.counts[1] = ubase;
+  }
+}
+
 __global__ void beam_finalize_kernel(gram_beam_state_t st, int nret, int max_length, int cur_len, int64_t* __restrict__ sequences,
                                      float* __restrict__ scores, int32_t* __restrict__ out_width) {
   const int b = blockIdx.x;
@@ -443,7 +504,8 @@ extern "C" int gram_beam_init(const gram_beam_state_t* st, const gram_trie_t* tr
 }
 
 static int launch_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, const float* lse, int V,
-                            int cur_len, int rows_per_user, const void* hd, const void* emb, int d, void* stream) {
+                            int cur_len, int rows_per_user, const void* hd, const void* emb, int d, const int32_t* rowpos,
+                            void* stream) {
   if (int e = check_state(st)) return e;
   if (!tr || !lse || cur_len < 1 || cur_len >= st->Tmax || V < 2 || (rows_per_user != 1 && rows_per_user != st->K)) return GRAM_E_ARG;
   if (!logits && (!hd || !emb || d < 64 || (d & 63))) return GRAM_E_ARG;
@@ -461,7 +523,7 @@ static int launch_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, 
   }
   gram_prof::Scope prof(GRAM_K_BEAM, (hipStream_t)stream, 0.0);
   hipLaunchKernelGGL(beam_step_kernel, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc,
-                     rows_per_user, (const bf16*)hd, (const bf16*)emb, d);
+                     rows_per_user, (const bf16*)hd, (const bf16*)emb, d, rowpos);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -469,13 +531,29 @@ static int launch_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, 
 extern "C" int gram_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, const float* lse, int V,
                               int cur_len, int rows_per_user, void* stream) {
   if (!logits) return GRAM_E_ARG;
-  return launch_beam_step(st, tr, logits, lse, V, cur_len, rows_per_user, nullptr, nullptr, 0, stream);
+  return launch_beam_step(st, tr, logits, lse, V, cur_len, rows_per_user, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int gram_beam_step_sparse(const gram_beam_state_t* st, const gram_trie_t* tr, const void* hidden_bf16,
                                      const void* lm_head_bf16, int d, const float* lse, int V, int cur_len, int rows_per_user,
                                      void* stream) {
-  return launch_beam_step(st, tr, nullptr, lse, V, cur_len, rows_per_user, hidden_bf16, lm_head_bf16, d, stream);
+  return launch_beam_step(st, tr, nullptr, lse, V, cur_len, rows_per_user, hidden_bf16, lm_head_bf16, d, nullptr, stream);
+}
+
+extern "C" int gram_beam_step_sparse_live(const gram_beam_state_t* st, const gram_trie_t* tr, const void* hidden_bf16,
+                                          const void* lm_head_bf16, int d, const float* lse, int V, int cur_len,
+                                          const int32_t* rowpos, void* stream) {
+  if (!rowpos || !st) return GRAM_E_ARG;
+  return launch_beam_step(st, tr, nullptr, lse, V, cur_len, st->K, hidden_bf16, lm_head_bf16, d, rowpos, stream);
+}
+
+extern "C" int gram_live_rows(const gram_beam_state_t* st, const gram_trie_t* tr, const gram_live_rows_t* out, void* stream) {
+  if (int e = check_state(st)) return e;
+  if (!tr || !out || !out->rows || !out->rowpos || !out->users || !out->tokens || !out->counts) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_BEAM, (hipStream_t)stream, 0.0);
+  hipLaunchKernelGGL(live_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *st, *tr, *out);
+  GRAM_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int gram_greedy_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, int V, int cur_len,

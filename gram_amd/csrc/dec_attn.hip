@@ -36,7 +36,8 @@ struct StepRegs {
 template <int NT>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
     const bf16* __restrict__ q, const bf16* __restrict__ kbank, const bf16* __restrict__ vtbank,
-    const uint8_t* __restrict__ mask, bf16* __restrict__ out, int K, int H, int S) {
+    const uint8_t* __restrict__ mask, bf16* __restrict__ out, int K, int H, int S, const int32_t* __restrict__ users,
+    const int32_t* __restrict__ rowpos) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NB = NT * 16;                               // padded beams
   float* sm_m = reinterpret_cast<float*>(smem);             // [4][NB]
@@ -44,7 +45,9 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
   float* sm_o = sm_l + 4 * NB;                              // [4][NB][64]
   unsigned long long* sm_valid = reinterpret_cast<unsigned long long*>(sm_o + 4 * NB * 64);  // [2] valid-step bits
 
-  const int h = blockIdx.x, b = blockIdx.y;
+  // live-row step (users != NULL): workgroup y serves user users[y]; q/out rows are the compact rows rowpos[b*K + beam]
+  // (-1 = beam not live: zero query, nothing stored)
+  const int h = blockIdx.x, b = users ? users[blockIdx.y] : blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int inner = H * 64;
@@ -56,9 +59,11 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int beam = 16 * nt + c;
+    int qrow = beam < K ? b * K + beam : -1;
+    if (rowpos && qrow >= 0) qrow = rowpos[qrow];
 #pragma unroll
     for (int kd = 0; kd < 2; ++kd)
-      qf[nt][kd] = beam < K ? ld_global_b128(q + ((size_t)b * K + beam) * inner + h * 64 + 32 * kd + 8 * g) : zero_bf16x8();
+      qf[nt][kd] = qrow >= 0 ? ld_global_b128(q + (size_t)qrow * inner + h * 64 + 32 * kd + 8 * g) : zero_bf16x8();
   }
 
   f32x4 o[4][NT];
@@ -229,13 +234,14 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
     bf16x4 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = (bf16)(acc[e] * inv);
-    *reinterpret_cast<bf16x4*>(out + ((size_t)b * K + beam) * inner + h * 64 + d4) = r;
+    const int orow = rowpos ? rowpos[b * K + beam] : b * K + beam;
+    if (orow >= 0) *reinterpret_cast<bf16x4*>(out + (size_t)orow * inner + h * 64 + d4) = r;
   }
 }
 
 template <int NT>
 int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int S,
-                 hipStream_t st) {
+                 const int32_t* users, const int32_t* rowpos, hipStream_t st) {
   const size_t smem = (size_t)(2 * 4 * NT * 16 + 4 * NT * 16 * 64) * sizeof(float) + 16;
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
@@ -245,7 +251,7 @@ int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* ma
     attr_set = true;
   }
   hipLaunchKernelGGL(cross_attn_kernel<NT>, dim3(H, B), dim3(256), smem, st, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
-                     mask, (bf16*)out, K, H, S);
+                     mask, (bf16*)out, K, H, S, users, rowpos);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -254,10 +260,13 @@ int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* ma
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kcache,
                                                             bf16* __restrict__ vcache, const int32_t* __restrict__ anc,
                                                             const float* __restrict__ bias, bf16* __restrict__ out, int R,
-                                                            int H, int t) {
-  const int r = blockIdx.x, i = threadIdx.x;  // i: 16 threads per head, 4 dims each
+                                                            int H, int t, const int32_t* __restrict__ rows) {
+  // live-row step (rows != NULL): qkv/out are indexed by the compact row, the cache and the ancestor table by the
+  // original row rows[compact]; R stays the row count of the cache
+  const int rc = blockIdx.x, i = threadIdx.x;  // i: 16 threads per head, 4 dims each
+  const int r = rows ? rows[rc] : rc;
   const int inner = H * 64, h = i >> 4;
-  const bf16* row = qkv + (size_t)r * 3 * inner + 4 * i;
+  const bf16* row = qkv + (size_t)rc * 3 * inner + 4 * i;
   const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(row);
   const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(row + inner);
   const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(row + 2 * inner);
@@ -292,30 +301,53 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restri
   bf16x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[e] * inv);
-  *reinterpret_cast<bf16x4*>(out + (size_t)r * inner + 4 * i) = o;
+  *reinterpret_cast<bf16x4*>(out + (size_t)rc * inner + 4 * i) = o;
 }
 
 }  // namespace
 
-extern "C" int gram_cross_attn_decode(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
-                                      int B, int K, int H, int S, void* stream) {
+static int cross_attn(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out, int B, int K,
+                      int H, int S, const int32_t* users, const int32_t* rowpos, void* stream) {
   if (B < 1 || K < 1 || K > GRAM_MAX_BEAMS || H < 1 || S < 32 || (S & 31) || S > 4096) return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   gram_prof::Scope prof(GRAM_K_CROSS_ATTN, st, 4.0 * B * H * S * 64);  // K + V^T, bf16
   switch ((K + 15) / 16) {
-    case 1: return launch_cross<1>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
-    case 2: return launch_cross<2>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
-    case 3: return launch_cross<3>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
-    default: return launch_cross<4>(q, k_layer, vt_layer, mask, out, B, K, H, S, st);
+    case 1: return launch_cross<1>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, st);
+    case 2: return launch_cross<2>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, st);
+    case 3: return launch_cross<3>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, st);
+    default: return launch_cross<4>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, st);
   }
+}
+
+extern "C" int gram_cross_attn_decode(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
+                                      int B, int K, int H, int S, void* stream) {
+  return cross_attn(q, k_layer, vt_layer, mask, out, B, K, H, S, nullptr, nullptr, stream);
+}
+
+extern "C" int gram_cross_attn_decode_live(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
+                                           int n_users, const int32_t* users, const int32_t* rowpos, int K, int H, int S,
+                                           void* stream) {
+  if (!users || !rowpos) return GRAM_E_ARG;
+  return cross_attn(q, k_layer, vt_layer, mask, out, n_users, K, H, S, users, rowpos, stream);
+}
+
+static int dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias, void* out, int R,
+                         int n_rows, const int32_t* rows, int H, int t, int Tmax, void* stream) {
+  if (R < 1 || n_rows < 1 || n_rows > R || H < 1 || H > 16 || t < 0 || t >= Tmax || Tmax > GRAM_MAX_DEC_LEN) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_DEC_SELF_ATTN, (hipStream_t)stream, 4.0 * n_rows * H * 64 * (t + 1));
+  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(n_rows), dim3(H * 16), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)kcache,
+                     (bf16*)vcache, anc, bias, (bf16*)out, R, H, t, rows);
+  GRAM_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int gram_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias, void* out,
                                   int R, int H, int t, int Tmax, void* stream) {
-  if (R < 1 || H < 1 || H > 16 || t < 0 || t >= Tmax || Tmax > GRAM_MAX_DEC_LEN) return GRAM_E_ARG;
-  gram_prof::Scope prof(GRAM_K_DEC_SELF_ATTN, (hipStream_t)stream, 4.0 * R * H * 64 * (t + 1));
-  hipLaunchKernelGGL(dec_self_attn_kernel, dim3(R), dim3(H * 16), 0, (hipStream_t)stream, (const bf16*)qkv, (bf16*)kcache,
-                     (bf16*)vcache, anc, bias, (bf16*)out, R, H, t);
-  GRAM_CHECK_LAUNCH();
-  return 0;
+  return dec_self_attn(qkv, kcache, vcache, anc, bias, out, R, R, nullptr, H, t, Tmax, stream);
+}
+
+extern "C" int gram_dec_self_attn_live(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias,
+                                       void* out, int R, int n_rows, const int32_t* rows, int H, int t, int Tmax, void* stream) {
+  if (!rows) return GRAM_E_ARG;
+  return dec_self_attn(qkv, kcache, vcache, anc, bias, out, R, n_rows, rows, H, t, Tmax, stream);
 }

@@ -63,6 +63,7 @@ struct Workspace {
   float* lse_part;  // [R][V/64][2]
   // beam state
   gram_beam_state_t beam;
+  gram_live_rows_t live;
   int32_t* width;
   int64_t bytes;
 };
@@ -114,6 +115,11 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   s.hyp_len = cv.take<int32_t>((int64_t)B * (K + 1));
   s.hyp_tok = cv.take<int32_t>((int64_t)B * (K + 1) * Tmax);
   s.error = cv.take<int32_t>(4);
+  w.live.rows = cv.take<int32_t>(R);
+  w.live.rowpos = cv.take<int32_t>(R);
+  w.live.users = cv.take<int32_t>(B);
+  w.live.tokens = cv.take<int32_t>(R);
+  w.live.counts = cv.take<int32_t>(4);
   w.width = cv.take<int32_t>(4);
   w.bytes = (cv.off + 255) & ~(int64_t)255;
   return w;
@@ -193,12 +199,31 @@ int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const ui
   return 0;
 }
 
-// K = beams per user in THIS step's rows (1 for the compact step 0), R_cache = rows of the cache slots
+struct LiveStep {  // host view of gram_live_rows_t after the counts came back
+  int n_rows, n_users;
+  const int32_t *rows, *rowpos, *users;
+};
+
+// K = beams per user in THIS step's rows (1 for the compact step 0), R_cache = rows of the cache slots.
+// live != NULL: the step runs on live->n_rows compact rows (tokens = their tokens), see gram_live_rows_t.
 int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, const int32_t* anc, const uint8_t* mask, int B,
-                int N, int L, int K, int R_cache, int Tmax, int t, float* logits, float* lse_part, void* st) {
+                int N, int L, int K, int R_cache, int Tmax, int t, float* logits, float* lse_part, const LiveStep* live,
+                void* st) {
   const gram_model_desc_t& c = m->d;
   const int d = c.d_model, inner = c.n_heads * 64, F = c.d_ff, H = c.n_heads, V = c.vocab;
-  const int R = B * K, S = N * L;
+  const int R = live ? live->n_rows : B * K, S = N * L;
+  auto self_attn = [&](int i, size_t cache_layer) {
+    return live ? gram_dec_self_attn_live(w.qkvd, w.kcache + i * cache_layer, w.vcache + i * cache_layer, anc, c.dec_bias_f32,
+                                          w.attnd, R_cache, R, live->rows, H, t, Tmax, st)
+                : gram_dec_self_attn(w.qkvd, w.kcache + i * cache_layer, w.vcache + i * cache_layer, anc, c.dec_bias_f32, w.attnd,
+                                     R, H, t, Tmax, st);
+  };
+  auto cross_attn = [&](int i, size_t bank_layer) {
+    return live ? gram_cross_attn_decode_live(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd,
+                                              live->n_users, live->users, live->rowpos, K, H, S, st)
+                : gram_cross_attn_decode(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd, B, K, H, S,
+                                         st);
+  };
   const size_t bank_layer = (size_t)B * H * S * 64;
   const size_t cache_layer = (size_t)Tmax * R_cache * inner;
   if (c.fold_norm) {
@@ -208,12 +233,11 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
     for (int i = 0; i < c.n_dec_layers; ++i) {
       TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
       TRY(gram_gemm_bf16_ex(w.hd, m->dec_wqkv[i], w.qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
-      TRY(gram_dec_self_attn(w.qkvd, w.kcache + i * cache_layer, w.vcache + i * cache_layer, anc, c.dec_bias_f32, w.attnd, R, H,
-                             t, Tmax, st));
+      TRY(self_attn(i, cache_layer));
       TRY(gram_gemm_bf16_ex(w.attnd, m->dec_wo[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
       TRY(gram_gemm_bf16_ex(w.hd, m->dec_wq_x[i], w.qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, &consume, st));
-      TRY(gram_cross_attn_decode(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd, B, K, H, S, st));
+      TRY(cross_attn(i, bank_layer));
       TRY(gram_gemm_bf16_ex(w.attnd, m->dec_wo_x[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
       TRY(gram_gemm_bf16_ex(w.hd, m->dec_wi[i], w.ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
@@ -224,12 +248,11 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   for (int i = 0; i < c.n_dec_layers; ++i) {
     TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln1[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
     TRY(gram_gemm_bf16(w.hd, m->dec_wqkv[i], w.qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, st));
-    TRY(gram_dec_self_attn(w.qkvd, w.kcache + i * cache_layer, w.vcache + i * cache_layer, anc, c.dec_bias_f32, w.attnd, R, H, t,
-                           Tmax, st));
+    TRY(self_attn(i, cache_layer));
     TRY(gram_gemm_bf16(w.attnd, m->dec_wo[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, st));
     TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln2[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
     TRY(gram_gemm_bf16(w.hd, m->dec_wq_x[i], w.qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, st));
-    TRY(gram_cross_attn_decode(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd, B, K, H, S, st));
+    TRY(cross_attn(i, bank_layer));
     TRY(gram_gemm_bf16(w.attnd, m->dec_wo_x[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, st));
     TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln3[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
     TRY(gram_gemm_bf16(w.hd, m->dec_wi[i], w.ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, st));
@@ -332,7 +355,7 @@ extern "C" int gram_decode_step(const gram_model_t* m, const int32_t* tokens, co
   if (t < 0 || t >= max_length - 1 || !logits) return GRAM_E_ARG;
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
-  return decode_step(m, w, tokens, anc, mask, B, N, L, K, B * K, max_length, t, logits, nullptr, stream);
+  return decode_step(m, w, tokens, anc, mask, B, N, L, K, B * K, max_length, t, logits, nullptr, nullptr, stream);
 }
 
 extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K,
@@ -366,11 +389,15 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
   TRY(gram_beam_init(&w.beam, trie, /*decoder_start_token_id=*/0, stream));
   if (K == 1) {  // HF: num_beams == 1 -> greedy_search (raw logits, no hypotheses, no scores)
     for (int t = 0; t + 1 < max_length; ++t) {
-      TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, 1, B, max_length, t, w.logits, nullptr, stream));
+      TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, 1, B, max_length, t, w.logits, nullptr, nullptr, stream));
       TRY(gram_greedy_step(&w.beam, trie, w.logits, m->d.vocab, t + 1, stream));
     }
     TRY(gram_greedy_finalize(&w.beam, max_length, sequences, w.width, stream));
   } else {
+  static const bool live_rows = [] {
+    const char* e = getenv("GRAM_LIVE_ROWS");
+    return !(e && e[0] == '0');
+  }();
   // fixed max_length-1 steps: finished users are padded exactly as BeamSearchScorer.process
   // pads them, so skipping HF's all-done early exit changes nothing and needs no host sync
   for (int t = 0; t + 1 < max_length; ++t) {
@@ -378,8 +405,31 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
     // the cross-attention and the lm_head run on ONE row per user (HF runs K identical rows);
     // gram_beam_step reads that shared row and points every beam's slot-0 ancestor at it
     const int Kt = t == 0 ? 1 : K;
+    // From the step after the shortest candidate's EOS on, beams have left the Trie (gram_live_rows_t): the decoder
+    // runs on the live rows only.  This costs the loop's one host round trip per such step (8 bytes), which is why
+    // it is tried only where the Trie says rows can be dead -- with ids of l or l+1 pieces, the last step.
+    if (live_rows && t >= 1 && trie->min_seq_len >= 2 && t >= trie->min_seq_len - 1) {
+      int32_t counts[2] = {0, 0};
+      TRY(gram_live_rows(&w.beam, trie, &w.live, stream));
+      hipError_t e = hipMemcpyAsync(counts, w.live.counts, sizeof(counts), hipMemcpyDeviceToHost, (hipStream_t)stream);
+      if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+      if (e != hipSuccess) return (int)e;
+      if (counts[0] < 0 || counts[0] > B * K || counts[1] < 0 || counts[1] > B) return GRAM_E_BEAM;
+      if (counts[0] < B * K) {
+        if (counts[0] > 0) {
+          const LiveStep live{counts[0], counts[1], w.live.rows, w.live.rowpos, w.live.users};
+          TRY(decode_step(m, w, w.live.tokens, w.beam.anc, mask, B, N, L, K, B * K, max_length, t, nullptr, w.lse_part, &live,
+                          stream));
+          TRY(gram_lse_combine(w.lse_part, w.lse, counts[0], m->d.vocab / 64, stream));
+        }  // else: no beam can be extended; the search step below reads no decoder row
+        TRY(gram_beam_step_sparse_live(&w.beam, trie, w.hd, m->d.lm_head_bf16, m->d.d_model, w.lse, m->d.vocab, t + 1,
+                                       w.live.rowpos, stream));
+        continue;
+      }
+    }
     // the [rows][V] logits are never written: LSE partials from the lm_head epilogue + sparse logits in the beam kernel
-    TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, Kt, B * K, max_length, t, nullptr, w.lse_part, stream));
+    TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, Kt, B * K, max_length, t, nullptr, w.lse_part, nullptr,
+                    stream));
     TRY(gram_lse_combine(w.lse_part, w.lse, B * Kt, m->d.vocab / 64, stream));
     TRY(gram_beam_step_sparse(&w.beam, trie, w.hd, m->d.lm_head_bf16, m->d.d_model, w.lse, m->d.vocab, t + 1, Kt, stream));
   }

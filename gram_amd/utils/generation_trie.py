@@ -108,15 +108,21 @@ class FlatTrie:
             raise ValueError("FlatTrie: append_trie is not supported (never set by the GRAM runners)")
         off, toks, nodes = [0], [], []
         queue = [trie.trie_dict]
+        depth = [0]
         head = 0
+        min_leaf = 0  # tokens on the path to the shallowest leaf = the shortest candidate sequence
         while head < len(queue):
             node = queue[head]
-            head += 1
+            if not node and head > 0 and (min_leaf == 0 or depth[head] < min_leaf):
+                min_leaf = depth[head]
             for tok in sorted(node.keys()):
                 toks.append(int(tok))
                 nodes.append(len(queue))
                 queue.append(node[tok])
+                depth.append(depth[head] + 1)
+            head += 1
             off.append(len(toks))
+        self.min_seq_len = int(min_leaf)
         self.child_off = np.asarray(off, dtype=np.int32)
         self.child_tok = np.asarray(toks, dtype=np.int32)
         self.child_node = np.asarray(nodes, dtype=np.int32)
@@ -148,6 +154,7 @@ class FlatTrie:
             t_off = torch.from_numpy(self.child_off).to(device)
             t_tok = torch.from_numpy(self.child_tok).to(device)
             t_node = torch.from_numpy(self.child_node).to(device)
-            c = _lib.Trie(t_off.data_ptr(), t_tok.data_ptr(), t_node.data_ptr(), self.n_nodes, self.n_edges, self.max_fanout)
+            c = _lib.Trie(t_off.data_ptr(), t_tok.data_ptr(), t_node.data_ptr(), self.n_nodes, self.n_edges, self.max_fanout,
+                          self.min_seq_len)
             self._device[key] = (c, (t_off, t_tok, t_node))
         return self._device[key]

@@ -145,6 +145,8 @@ typedef struct {
   const int32_t* child_tok;
   const int32_t* child_node;
   int32_t n_nodes, n_edges, max_fanout;
+  int32_t min_seq_len; /* shortest candidate sequence, start token and EOS included; 0 = unknown (gram_generate then
+                          never tries the live-row compaction below) */
 } gram_trie_t;
 
 /* Beam-search state for B users x K beams (HF transformers 4.26 beam_search + BeamSearchScorer
@@ -189,6 +191,34 @@ int gram_beam_step(const gram_beam_state_t* st_host, const gram_trie_t* trie_hos
 int gram_beam_step_sparse(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const void* hidden_bf16,
                           const void* lm_head_bf16, int d, const float* lse, int V, int cur_len, int rows_per_user,
                           void* stream);
+
+/* Live rows.  When a beam emits EOS its hypothesis moves to the heap and HF refills the slot with a -inf candidate
+ * (BeamSearchScorer.process); such a row, and every row of a finished user, can only produce -inf candidates from then
+ * on, so nothing downstream reads its decoder output -- but the reference still runs the decoder on it.  With item
+ * ids of l or l+1 pieces most rows of the last step are in that state.  gram_live_rows compacts the
+ * others (ascending, so grouped by user); the *_live variants of the per-row kernels then work on compact rows while
+ * the self-attention cache, the ancestor table, the bank and the beam state keep their original indexing.
+ * Results are bit-identical to running every row (every kernel of the step is row-independent). */
+typedef struct {
+  int32_t* rows;   /* [R]  original row of compact row i                                   */
+  int32_t* rowpos; /* [R]  compact row of original row r, -1 = not live                    */
+  int32_t* users;  /* [B]  users owning at least one live row, ascending                   */
+  int32_t* tokens; /* [R]  decoder input token of compact row i                            */
+  int32_t* counts; /* [2]  number of live rows, number of such users                       */
+} gram_live_rows_t;
+int gram_live_rows(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const gram_live_rows_t* out_host,
+                   void* stream);
+/* gram_dec_self_attn on n_rows compact rows: qkv/out [n_rows][..] compact, cache/anc rows = rows[i] of R. */
+int gram_dec_self_attn_live(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias,
+                            void* out, int R, int n_rows, const int32_t* rows, int H, int t, int Tmax, void* stream);
+/* gram_cross_attn_decode for the n_users users in `users`; q/out rows = rowpos[user*K + beam] (skipped if -1). */
+int gram_cross_attn_decode_live(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask,
+                                void* out, int n_users, const int32_t* users, const int32_t* rowpos, int K, int H,
+                                int S, void* stream);
+/* gram_beam_step_sparse with hidden/lse indexed by compact row (all B users are stepped). */
+int gram_beam_step_sparse_live(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const void* hidden_bf16,
+                               const void* lm_head_bf16, int d, const float* lse, int V, int cur_len,
+                               const int32_t* rowpos, void* stream);
 
 /* HF 4.26 greedy_search (generate with num_beams == 1; BASELINE configs[0]) on the same state with K = 1:
  * argmax of the RAW logits over the Trie children (first maximum), finished users emit pad; finalize copies

@@ -221,6 +221,44 @@ def test_passage_cache_is_result_neutral(gpu, backbone, N, L, K):
     assert m._pcache is None
 
 
+@pytest.mark.parametrize("dataset,K", [("Beauty", 20), ("Toys", 8)])
+def test_live_row_compaction_is_result_neutral(gpu, dataset, K):
+    """Last decode step(s) on the live rows only (gram_live_rows_t: beams that left the Trie at EOS are skipped) vs every
+    row: bit-identical sequences and scores on the real item Tries (ids of l or l+1 pieces), and the compact step
+    really ran (the cross-attention streamed fewer users' banks)."""
+    import ctypes as C
+    from gram_amd import _lib
+    from gram_amd.utils import generation_trie as gt
+    oc, sd, m = _model(gpu, "small", 11)
+    cands = _trie_cands(dataset)
+    fn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
+    g = torch.Generator().manual_seed(5)
+    B, N, L = 40, 2, 32
+    ids, mask = _realistic_inputs(g, B, N, L, lo=8)
+    lib = _lib.load()
+
+    def run():
+        _lib.check(lib.gram_prof_enable(1 << _lib.K_CROSS_ATTN, 4096), "prof")
+        out = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max(len(c) for c in cands),
+                         prefix_allowed_tokens_fn=fn, num_beams=K, num_return_sequences=K, length_penalty=1.0)
+        ms, n, work, dropped = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_int64(0)
+        _lib.check(lib.gram_prof_collect(_lib.K_CROSS_ATTN, C.byref(ms), C.byref(n), C.byref(work), C.byref(dropped)), "collect")
+        lib.gram_prof_enable(0, 0)
+        return out["sequences"].cpu(), out["sequences_scores"].cpu(), work.value
+
+    flat = m._flat_trie(fn)
+    assert flat.min_seq_len == min(len(c) for c in cands) and flat.min_seq_len < max(len(c) for c in cands)
+    seq_live, sc_live, work_live = run()
+    keep = flat.min_seq_len
+    flat.min_seq_len, flat._device = 0, {}  # unknown shortest candidate: gram_generate runs every row of every step
+    try:
+        seq_all, sc_all, work_all = run()
+    finally:
+        flat.min_seq_len, flat._device = keep, {}
+    assert torch.equal(seq_live, seq_all) and torch.equal(sc_live, sc_all)
+    assert work_live < work_all, (work_live, work_all)
+
+
 def test_runner_end_to_end_with_collator(gpu, tmp_path):
     """The drop-in flow of single_runner_gram.py:570-719 on the GPU path: texts -> CollatorGRAM (stub tokenizer) ->
     DataLoader -> get_runner("single").test_dataset_task -> Trie from the candidate strings, generate, decode, metrics,
