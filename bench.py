@@ -206,7 +206,8 @@ def main():
                         f"{N} granularity passages x {L} tokens (S={N * L}), beam={K} top-{K}"
                         + (f"; item passages drawn from {args.item_pool} prompts and served by the passage cache "
                            f"(NOT the headline configuration)" if item_cache else ""),
-            "ragged": bool(args.ragged), "item_cache": item_cache, "users_per_step_per_gpu": B, "parallelism": f"dp{world} (users sharded, no data-path collective)",
+            "ragged": bool(args.ragged), "item_cache": item_cache,
+            "live_row_compaction": os.environ.get("GRAM_LIVE_ROWS", "1") != "0", "users_per_step_per_gpu": B, "parallelism": f"dp{world} (users sharded, no data-path collective)",
             "precision": "bf16 operands / fp32 accumulate, fp32 residual stream, softmax and scores",
         },
         "output_check": {"sequences_shape": list(out["sequences"].shape),
@@ -214,6 +215,8 @@ def main():
                                                  for s in out["sequences"][: 2 * K].cpu().tolist()))},
     }
     if kernel:
+        # decode steps that actually launched the cross-attention (the live-row compaction drops a step whose rows are all dead)
+        result["config"]["cross_attn_launches_per_generate"] = kernel["cross_attn"]["launches"] // args.steps
         steps = args.steps
         result["kernel_ms_per_step"] = {k: round(v["ms"] / steps, 4) for k, v in kernel.items()}
         result["kernel_ms_per_step"]["sum"] = round(sum(v["ms"] for v in kernel.values()) / steps, 4)

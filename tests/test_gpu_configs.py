@@ -221,6 +221,91 @@ def test_passage_cache_is_result_neutral(gpu, backbone, N, L, K):
     assert m._pcache is None
 
 
+def _rand_cands(seed, n_items, lo, hi, alphabet=40):
+    import random
+    rng = random.Random(seed)
+    out = set()
+    while len(out) < n_items:
+        out.add(tuple([0] + [rng.randrange(2, alphabet) for _ in range(rng.randint(lo, hi))] + [1]))
+    return [list(c) for c in sorted(out)]
+
+
+def test_live_rows_kernel_matches_numpy(gpu):
+    """gram_live_rows against numpy on a random beam state: live = user not done and the beam's node has children."""
+    import ctypes as C
+    from gram_amd import _lib
+    from gram_amd.utils import generation_trie as gt
+    lib = _lib.load()
+    cands = _rand_cands(3, 300, 2, 6)
+    flat = gt.FlatTrie(gt.Trie(cands))
+    ctrie, _keep = flat.to_device(DEV)
+    g = torch.Generator().manual_seed(9)
+    for B, K in [(1, 1), (7, 20), (1500, 20), (333, 64)]:
+        R = B * K
+        node = torch.randint(-1, flat.n_nodes, (R,), generator=g, dtype=torch.int32)
+        done = (torch.rand(B, generator=g) < 0.3).to(torch.int32)
+        tokens = torch.randint(0, 1000, (R,), generator=g, dtype=torch.int32)
+        i32 = dict(dtype=torch.int32, device=DEV)
+        t = dict(tokens=tokens.to(DEV), node=node.to(DEV), done=done.to(DEV))
+        st = _lib.BeamState(B=B, K=K, Tmax=8, length_penalty=1.0, eos=1, pad=0, tokens=t["tokens"].data_ptr(),
+                            node=t["node"].data_ptr(), done=t["done"].data_ptr())
+        o = dict(rows=torch.full((R,), -7, **i32), rowpos=torch.full((R,), -7, **i32), users=torch.full((B,), -7, **i32),
+                 tokens=torch.full((R,), -7, **i32), counts=torch.full((4,), -7, **i32))
+        live = _lib.LiveRows(**{k: v.data_ptr() for k, v in o.items()})
+        _lib.check(lib.gram_live_rows(C.byref(st), C.byref(ctrie), C.byref(live), torch.cuda.current_stream().cuda_stream), "live")
+        torch.cuda.synchronize()
+        fan = np.diff(flat.child_off)
+        nd = node.numpy()
+        alive = (np.repeat(done.numpy(), K) == 0) & (nd >= 0) & (fan[np.clip(nd, 0, None)] > 0)
+        rows = np.nonzero(alive)[0]
+        users = np.nonzero(alive.reshape(B, K).any(1))[0]
+        assert o["counts"][:2].tolist() == [len(rows), len(users)]
+        assert o["rows"][: len(rows)].cpu().numpy().tolist() == rows.tolist()
+        assert o["users"][: len(users)].cpu().numpy().tolist() == users.tolist()
+        pos = np.full(R, -1)
+        pos[rows] = np.arange(len(rows))
+        assert o["rowpos"].cpu().numpy().tolist() == pos.tolist()
+        assert o["tokens"][: len(rows)].cpu().numpy().tolist() == tokens.numpy()[rows].tolist()
+
+
+def test_live_row_compaction_partial_steps(gpu):
+    """Candidates of 4..8 tokens: from step 3 on some beams have left the Trie while others go on, so steps run on a
+    strict subset of the rows (fewer self-attention rows, the same number of launches); results bit-identical to running
+    every row, and the beam search still equals the fp32 oracle's."""
+    import ctypes as C
+    from gram_amd import _lib
+    from gram_amd.utils import generation_trie as gt
+    oc, sd, m = _model(gpu, "small", 12)
+    cands = _rand_cands(5, 120, 2, 6)
+    fn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
+    g = torch.Generator().manual_seed(6)
+    B, N, L, K = 24, 2, 32, 8
+    ids, mask = _realistic_inputs(g, B, N, L, lo=8)
+    lib = _lib.load()
+
+    def run():
+        _lib.check(lib.gram_prof_enable(1 << _lib.K_DEC_SELF_ATTN, 4096), "prof")
+        out = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max(len(c) for c in cands),
+                         prefix_allowed_tokens_fn=fn, num_beams=K, num_return_sequences=K, length_penalty=1.0)
+        ms, n, work, dropped = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_int64(0)
+        _lib.check(lib.gram_prof_collect(_lib.K_DEC_SELF_ATTN, C.byref(ms), C.byref(n), C.byref(work), C.byref(dropped)), "collect")
+        lib.gram_prof_enable(0, 0)
+        return out["sequences"].cpu(), out["sequences_scores"].cpu(), work.value, n.value
+
+    flat = m._flat_trie(fn)
+    assert flat.min_seq_len == 4
+    seq_live, sc_live, work_live, n_live = run()
+    flat.min_seq_len, flat._device = 0, {}
+    try:
+        seq_all, sc_all, work_all, n_all = run()
+    finally:
+        flat.min_seq_len, flat._device = 4, {}
+    assert torch.equal(seq_live, seq_all) and torch.equal(sc_live, sc_all)
+    assert n_live == n_all and work_live < 0.9 * work_all, (n_live, n_all, work_live, work_all)
+    ref = O.generate(sd, oc, ids[:4], mask[:4], max(len(c) for c in cands), O.prefix_allowed_tokens_fn(O.Trie(cands)), K, K, 1.0)
+    _check_generate(oc, sd, dict(sequences=seq_live[: 4 * K], sequences_scores=sc_live[: 4 * K]), ref, ids[:4], mask[:4], cands, K, 0.02)
+
+
 @pytest.mark.parametrize("dataset,K", [("Beauty", 20), ("Toys", 8)])
 def test_live_row_compaction_is_result_neutral(gpu, dataset, K):
     """Last decode step(s) on the live rows only (gram_live_rows_t: beams that left the Trie at EOS are skipped) vs every
