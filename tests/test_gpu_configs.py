@@ -418,3 +418,47 @@ def test_runner_end_to_end_with_collator(gpu, tmp_path):
         assert plan[0].n_cached == int(batch["item_text_masks"][:, 1:].any(-1).sum())  # every item passage is a hit
     assert open(args.pred_path).read() == open(str(tmp_path / "preds.tsv")).read()
     m.clear_passage_cache()
+
+
+def test_dataset_collator_runner_flow_with_passage_cache(gpu, tmp_path, monkeypatch):
+    """The whole drop-in data path on the fixture dataset directory: gram_amd.data.TestDatasetGRAM (reference-pinned,
+    tests/test_host_logic.py) -> CollatorGRAM -> get_runner("single").test_dataset_task.  The runner fills the passage
+    cache from dataset.item2input, every item passage of every user is then served from it, and the preds TSV is
+    identical to the run with --passage_cache 0."""
+    import json
+    from types import SimpleNamespace
+
+    from torch.utils.data import DataLoader
+
+    from gram_amd.data import TestDatasetGRAM
+    from gram_amd.processor import CollatorGRAM
+    from gram_amd.runner import get_runner
+    from tests.stub_tokenizer import StubTokenizer
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    monkeypatch.chdir(golden)
+    a = json.load(open(os.path.join(golden, "dataset_cases.json")))[0]["args"]
+    a.update(item_id_path="item_ids_alt.txt", id_linking=1, max_his=4, item_prompt_max_len=64, target_max_len=16,
+             item_id_type="split", metrics="hit@1,hit@5,ndcg@5", beam_size=5, length_penalty=1.0, save_predictions=True)
+    oc, sd, m = _model(gpu, "small", 13)
+    tok = StubTokenizer()
+    outs = {}
+    for cache in (1, 0):
+        args = SimpleNamespace(**a, passage_cache=cache, pred_path=str(tmp_path / f"preds_{cache}.tsv"))
+        ds = TestDatasetGRAM(args, "Beauty", "sequential", None, tok, mode="test")
+        loader = DataLoader(ds, batch_size=5, shuffle=False, collate_fn=CollatorGRAM(tok, args, mode="test"))
+        m.clear_passage_cache()
+        runner = get_runner("single", m, None, tok, None, None, None, DEV, args)
+        runner.test_dataset_task(loader)
+        assert runner.last_results["total"] == len(ds) == 12
+        if cache:
+            assert m._pcache["canon"].shape[0] == len(set(ds.item2input.values()))
+            for batch in loader:
+                plan = m._plan_encoder(batch["item_text_ids"].to(DEV), batch["item_text_masks"].to(DEV).view(torch.uint8),
+                                       *batch["item_text_ids"].shape)
+                assert plan[0].n_cached == int(batch["item_text_masks"][:, 1:].any(-1).sum())
+                assert plan[0].n_active - plan[0].n_cached == batch["item_text_ids"].shape[0]  # only the user prompts are encoded
+        else:
+            assert m._pcache is None
+        outs[cache] = open(args.pred_path).read()
+    assert outs[1] == outs[0] and outs[1].count("\n") >= 13
+    m.clear_passage_cache()

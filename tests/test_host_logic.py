@@ -154,3 +154,36 @@ def test_collator_matches_reference_fixtures(golden_dir):
     with pytest.raises(ValueError):
         CollatorGRAM(StubTokenizer(), args)([{"input": ["a b"], "output": "x", "user_id": "u"},
                                               {"input": ["a", "b", "c"], "output": "y", "user_id": "v"}])
+
+
+def test_dataset_and_indexing_match_reference_fixtures(golden_dir, monkeypatch):
+    """gram_amd.data.TestDatasetGRAM / gram_amd.utils.indexing.gram_indexing against the outputs of the reference's own
+    classes (test_dataset_gram.py:19-231, indexing.py:132-322) on the synthetic dataset directory
+    tests/golden/dataset_fixture (oracle/make_dataset_fixtures.py): every item_prompt kind, id_linking, max_his, history
+    order, validation/test hold-out, an alternative item id file, Amazon- and Yelp-style attribute lines."""
+    import json
+    from types import SimpleNamespace
+
+    from gram_amd.data import TestDatasetGRAM
+    from gram_amd.utils import indexing
+    cases = json.load(open(os.path.join(golden_dir, "dataset_cases.json")))
+    assert {c["args"]["item_prompt"] for c in cases} == {"all_text", "lexical_id", "nothing", "only_title", "only_brand",
+                                                         "only_category", "only_tbc"}
+    monkeypatch.chdir(golden_dir)  # the fixtures hold paths relative to tests/golden
+    for c in cases:
+        ds = TestDatasetGRAM(SimpleNamespace(**c["args"]), c["dataset"], "sequential", None, None, mode=c["mode"])
+        assert len(ds) == c["len"] and ds.all_items == c["all_items"]
+        assert ds.item2input == c["item2input"] and list(ds.item2input) == list(c["item2input"])
+        assert ds.item2lexid == c["item2lexid"] and ds.user_seq_dict == c["user_seq_dict"]
+        assert [ds[i] for i in range(len(ds))] == c["samples"]
+        assert [s["history"] for s in ds.data_samples] == c["history"] and sorted(ds.info) == c["info"]
+    # failure modes of the reference that callers rely on
+    a = dict(cases[0]["args"])
+    with pytest.raises(ValueError):
+        TestDatasetGRAM(SimpleNamespace(**a), "Beauty", "sequential", None, None, mode="train")
+    with pytest.raises(FileNotFoundError):  # indexing.py:169-172
+        indexing.gram_indexing("dataset_fixture", "Beauty", None, None, args=SimpleNamespace(**dict(a, hierarchical_id_type="nope")))
+    with pytest.raises(ValueError):  # text prompts need top_k_similar_item > 0 (indexing.py:183-207)
+        indexing.gram_indexing("dataset_fixture", "Beauty", None, None, args=SimpleNamespace(**dict(a, top_k_similar_item=0)))
+    with pytest.raises(AssertionError):
+        TestDatasetGRAM(SimpleNamespace(**a), "Beauty", "rating", None, None)
