@@ -332,6 +332,7 @@ class GRAM(nn.Module):
 
     # ------------------------------------------------------------------ which passages the encoder runs on
     _CACHE_L = _lib.GRAM_MAX_PASSAGE_LEN
+    _KEY_MULT: Dict[torch.device, torch.Tensor] = {}
 
     @staticmethod
     def _canonical(rows_ids: torch.Tensor, rows_mask: torch.Tensor) -> torch.Tensor:
@@ -343,8 +344,11 @@ class GRAM(nn.Module):
     def _passage_keys(canon: torch.Tensor) -> torch.Tensor:
         # 64-bit key, overflow-free ((id+1) < 2^15, multiplier < 2^31, 128 terms); a key match is always
         # confirmed against the stored tokens, so a collision costs a miss, never a wrong hit
-        g = torch.Generator().manual_seed(0x6772616D)
-        mult = torch.randint(1, 2 ** 31 - 1, (GRAM._CACHE_L,), generator=g, dtype=torch.int64).to(canon.device)
+        mult = GRAM._KEY_MULT.get(canon.device)
+        if mult is None:
+            g = torch.Generator().manual_seed(0x6772616D)
+            mult = torch.randint(1, 2 ** 31 - 1, (GRAM._CACHE_L,), generator=g, dtype=torch.int64).to(canon.device)
+            GRAM._KEY_MULT[canon.device] = mult
         return ((canon.to(torch.int64) + 1) * mult).sum(dim=1)
 
     @torch.no_grad()
