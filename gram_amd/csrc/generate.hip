@@ -132,6 +132,8 @@ int check_shapes(const gram_model* m, int B, int N, int L, int K, int Tmax) {
   return 0;
 }
 
+constexpr int kPrecomputedRsRows = 32768;  // = the row count from which gemm.hip dispatches to the ping-pong kernel
+
 #define TRY(x)            \
   do {                    \
     int e__ = (x);        \
@@ -147,14 +149,19 @@ int encoder_layers(const gram_model* m, const Workspace& w, const int64_t* ids, 
     // T5LayerNorm folded into the GEMMs around it (gram_norm_fusion_t): w.h holds xb = bf16(x), w.ss the
     // per-row sum-of-squares partials; both are refreshed by every residual GEMM's epilogue
     const gram_norm_fusion_t produce{w.h, w.ss, nullptr, 0, 0, 0.f};
-    const gram_norm_fusion_t consume{nullptr, nullptr, w.rs, 0, d, c.eps};  // 1/rms precomputed per row (one tiny kernel per norm)
+    // big problems (the ping-pong GEMMs, M >= kPrecomputedRsRows) take 1/rms precomputed per row by one tiny kernel per
+    // norm; below that the consumer GEMM adds the partials itself (same order, same bits) and the launch is saved --
+    // a small batch is a chain of ~1 500 dependent launches and nothing else
+    const bool pre_rs = Me >= kPrecomputedRsRows;
+    const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rs, 0, d, c.eps}
+                                              : gram_norm_fusion_t{nullptr, nullptr, w.ss, d / 64, d, c.eps};
     TRY(gram_embed_ex(c.embed_f32, ids, 1, w.x, w.h, w.ss, d / 64, Me, d, st));
     for (int i = 0; i < c.n_enc_layers; ++i) {
-      TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
+      if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
       TRY(gram_gemm_bf16_ex(w.h, m->enc_wqkv[i], w.qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
       TRY(gram_enc_self_attn(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, st));
       TRY(gram_gemm_bf16_ex(w.attn, m->enc_wo[i], w.x, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
-      TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
+      if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
       TRY(gram_gemm_bf16_ex(w.h, m->enc_wi[i], w.u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
       TRY(gram_gemm_bf16_ex(w.u, m->enc_wo2[i], w.x, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
     }
@@ -228,18 +235,20 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   const size_t cache_layer = (size_t)Tmax * R_cache * inner;
   if (c.fold_norm) {
     const gram_norm_fusion_t produce{w.hd, w.ssd, nullptr, 0, 0, 0.f};
-    const gram_norm_fusion_t consume{nullptr, nullptr, w.rsd, 0, d, c.eps};
+    const bool pre_rs = R >= kPrecomputedRsRows;  // see encoder_layers
+    const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rsd, 0, d, c.eps}
+                                              : gram_norm_fusion_t{nullptr, nullptr, w.ssd, d / 64, d, c.eps};
     TRY(gram_embed_ex(c.embed_f32, tokens, 0, w.xd, w.hd, w.ssd, d / 64, R, d, st));
     for (int i = 0; i < c.n_dec_layers; ++i) {
-      TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
       TRY(gram_gemm_bf16_ex(w.hd, m->dec_wqkv[i], w.qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
       TRY(self_attn(i, cache_layer));
       TRY(gram_gemm_bf16_ex(w.attnd, m->dec_wo[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
-      TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
       TRY(gram_gemm_bf16_ex(w.hd, m->dec_wq_x[i], w.qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, &consume, st));
       TRY(cross_attn(i, bank_layer));
       TRY(gram_gemm_bf16_ex(w.attnd, m->dec_wo_x[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
-      TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
       TRY(gram_gemm_bf16_ex(w.hd, m->dec_wi[i], w.ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
       TRY(gram_gemm_bf16_ex(w.ud, m->dec_wo2[i], w.xd, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
     }
