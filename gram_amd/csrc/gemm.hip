@@ -397,6 +397,84 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
 }
 
 // ---------------------------------------------------------------------------------------------
+// M <= 64 (one user, or a few: the decoder at the reference's default --eval_batch_size 1 is a chain of ~1 000 such
+// GEMMs).  A tiled kernel gives such a problem N/128 workgroups, each pulling a 128-column slab of W through one CU:
+// the weights arrive at a fraction of the HBM rate.  Here a workgroup owns 64 columns and each of its 4 waves ONE
+// 16-column n-tile over the whole K, operands straight from global memory (W rows are K-contiguous: a lane's 16 B are
+// the MFMA operand; A is a few KiB, L2-resident), 8 k-blocks of loads in flight.  The accumulators then meet in LDS and
+// wave 0 runs the common epilogue on the 64 x 64 tile, so every output bit equals the tiled kernels' (same MFMA
+// sequence per accumulator, same epilogue code).
+template <int EPI, int MT>  // MT = m-tiles of 16 rows that exist (M <= 16 * MT)
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
+                                                          int K, int lda, EpiArgs ep) {
+  __shared__ f32x4 xch[4][MT][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const bf16* wp = W + (size_t)(n0 + wave * 16 + r16) * K + g * 8;
+  const bf16* ap[MT];
+  bool a_ok[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    a_ok[j] = j * 16 + r16 < M;
+    ap[j] = A + (size_t)(a_ok[j] ? j * 16 + r16 : 0) * lda + g * 8;
+  }
+  f32x4 acc1[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) acc1[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // U k-blocks (32 wide) of loads in flight, then their MFMAs (a second register set with the next loads already under
+  // way was measured slower: 13.0 vs 11.4 ms of GEMM time per generate at B = 1)
+  constexpr int U = 8;
+  const int nkb = K >> 5;
+  for (int kb = 0; kb < nkb; kb += U) {
+    bf16x8 fw[U], fa[U][MT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = min(kb + u, nkb - 1) << 5;  // (past the end: a valid re-read, not used)
+      fw[u] = ld_global_b128(wp + k);
+#pragma unroll
+      for (int j = 0; j < MT; ++j) fa[u][j] = a_ok[j] ? ld_global_b128(ap[j] + k) : zero_bf16x8();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kb + u < nkb) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc1[j] = mfma16(fw[u], fa[u][j], acc1[j]);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < MT; ++j) xch[wave][j][lane] = acc1[j];
+  __syncthreads();
+  if (wave != 0) return;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = j < MT ? xch[i][j < MT ? j : 0][lane] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD) {
+    // the row-contiguous epilogue of the 128-row kernel (its sum-of-squares butterfly is the one every default path uses);
+    // the exchange buffer is free again: only this wave is left and its values are in registers
+    __builtin_amdgcn_wave_barrier();
+    epilogue_rows64<EPI>(acc, reinterpret_cast<char*>(&xch[0][0][0]), 0, n0, 0, 0, lane, M, ep);
+  } else {
+    float rs4[4];
+    load_row_scales(ep, 0, r16, M, rs4);
+    epilogue<EPI, 4>(acc, 0, n0, 0, 0, r16, g, M, ep, rs4);
+  }
+}
+
+template <int EPI>
+int launch_skinny(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+  if (M < 1 || M > 64 || N % 64 || K % 32) return GRAM_E_ARG;
+  const dim3 grid(N / 64), block(256);
+  if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
+  else if (M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int EPI, int WM, int NST, int TNW>
 __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void gemm_dma_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, int lda, EpiArgs ep) {
@@ -1704,9 +1782,16 @@ int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiAr
   return 0;
 }
 
+constexpr int V_SKINNY = 30;
+
 template <int EPI>
 int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
   gram_prof::Scope prof(GRAM_K_GEMM, st, 2.0 * M * N * K);
+  if constexpr (EPI != GRAM_EPI_KV_BANK) {
+    static const int use_skinny = getenv("GRAM_GEMM_SKINNY") ? atoi(getenv("GRAM_GEMM_SKINNY")) : 1;  // A/B hook
+    if (g_force_variant == V_SKINNY || (g_force_variant < 0 && use_skinny && M <= 64 && N % 64 == 0 && K % 32 == 0))
+      return launch_skinny<EPI>(A, W, M, N, K, lda, ep, st);
+  }
   if constexpr (EPI == GRAM_EPI_F32_LSE) {  // 64-column wave tiles only: the ping-pong kernel (partials only) or the 128-row kernels
     static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
     if ((g_force_variant == V_PP || (g_force_variant < 0 && use_pp == 1 && M >= 32768)) && !ep.C) {

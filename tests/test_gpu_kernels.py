@@ -101,6 +101,63 @@ def test_gemm_persistent_variants(G, M, N, K):
         assert torch.equal(outs[8][key], outs[22][key]), key
 
 
+@pytest.mark.parametrize("M", [1, 16, 20, 33, 64])
+@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (768, 3072), (1408, 512)])
+def test_gemm_skinny_matches_tiled(G, M, N, K):
+    """The M <= 64 kernel (variant 30: one 16-column n-tile per wave over the whole K, operands straight from global
+    memory, common epilogue on wave 0) against the tiled 128 x 128 kernel (variant 1): every epilogue bit for bit,
+    including the folded-norm consumer fed with the partial sums of squares, the producer outputs, and the lm_head's
+    (max, sum exp) partials."""
+    import ctypes as ct
+
+    from gram_amd import _lib
+    L_ = G.lib()
+    A, W = G.bf(_r(M, K, seed=21)), G.bf(_r(N, K, seed=22, scale=K ** -0.5))
+    ref = A.float() @ W.float().T
+    ssin = (torch.rand(M, K // 64, generator=torch.Generator().manual_seed(23)) * 64 + 1).to(G.DEV)
+    base = _r(M, N, seed=24).to(G.DEV)
+    outs = {}
+    try:
+        for v in (1, 30):
+            L_.gram_debug_set_gemm_variant(v)
+            o = {}
+            for epi in (_lib.EPI_BF16, _lib.EPI_BF16_RELU):
+                y = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+                G.gemm(A, W, epi, y)
+                o[("plain", epi)] = y
+                y2 = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+                cons = _lib.NormFusion(None, None, ssin.data_ptr(), K // 64, K, 1e-6)
+                _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(y2), M, N, K, K, N, epi, None, ct.byref(cons), G.stream()), "consumer")
+                o[("scaled", epi)] = y2
+            f = torch.zeros(M, N, dtype=torch.float32, device=G.DEV)
+            G.gemm(A, W, _lib.EPI_F32, f)
+            o["f32"] = f
+            x = base.clone()
+            xb = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+            ss = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=G.DEV)
+            prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
+            _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(x), M, N, K, K, N, _lib.EPI_F32_ADD, None, ct.byref(prod), G.stream()), "producer")
+            o["add"], o["xb"], o["ss"] = x, xb, ss
+            if N % 128 == 0:
+                part = torch.full((M, N // 64, 2), float("nan"), dtype=torch.float32, device=G.DEV)
+                _lib.check(L_.gram_gemm_bf16_lse(G.p(A), G.p(W), None, G.p(part), M, N, K, K, N, G.stream()), "lse")
+                o["lse"] = part
+            torch.cuda.synchronize()
+            outs[v] = o
+    finally:
+        L_.gram_debug_set_gemm_variant(-1)
+    o = outs[30]
+    rs = torch.rsqrt(ssin.sum(-1) / K + 1e-6)
+    assert torch.allclose(o[("plain", _lib.EPI_BF16)].float(), ref, atol=2e-2, rtol=1e-2)
+    assert torch.allclose(o[("scaled", _lib.EPI_BF16_RELU)].float(), (ref * rs[:, None]).clamp(min=0), atol=3e-2, rtol=1e-2)
+    assert torch.allclose(o["f32"], ref, atol=1e-3, rtol=1e-4) and torch.allclose(o["add"], base + ref, atol=2e-3, rtol=1e-4)
+    if "lse" in o:
+        lse = torch.logsumexp(torch.log(o["lse"][..., 1]) + o["lse"][..., 0], dim=-1)
+        assert torch.allclose(lse, torch.logsumexp(ref, dim=-1), atol=1e-3)
+    for key in outs[1]:
+        assert torch.equal(outs[1][key], outs[30][key]), key
+
+
 def test_gemm_asymmetric_identity(G):
     """A = I with an asymmetric W catches a transposed / row-col swapped fragment mapping."""
     from gram_amd import _lib
