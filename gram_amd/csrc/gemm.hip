@@ -404,20 +404,20 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
 // the MFMA operand; A is a few KiB, L2-resident), 8 k-blocks of loads in flight.  The accumulators then meet in LDS and
 // wave 0 runs the common epilogue on the 64 x 64 tile, so every output bit equals the tiled kernels' (same MFMA
 // sequence per accumulator, same epilogue code).
-template <int EPI, int MT>  // MT = m-tiles of 16 rows that exist (M <= 16 * MT)
+template <int EPI, int MT>  // MT = m-tiles of 16 rows per workgroup that exist (M <= 16 * MT, or MT = 4 and a grid row per 64 rows)
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
                                                           int K, int lda, EpiArgs ep) {
   __shared__ f32x4 xch[4][MT][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 64;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
   const bf16* wp = W + (size_t)(n0 + wave * 16 + r16) * K + g * 8;
   const bf16* ap[MT];
   bool a_ok[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
-    a_ok[j] = j * 16 + r16 < M;
-    ap[j] = A + (size_t)(a_ok[j] ? j * 16 + r16 : 0) * lda + g * 8;
+    a_ok[j] = m0 + j * 16 + r16 < M;
+    ap[j] = A + (size_t)(a_ok[j] ? m0 + j * 16 + r16 : 0) * lda + g * 8;
   }
   f32x4 acc1[MT];
 #pragma unroll
@@ -455,18 +455,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
     // the row-contiguous epilogue of the 128-row kernel (its sum-of-squares butterfly is the one every default path uses);
     // the exchange buffer is free again: only this wave is left and its values are in registers
     __builtin_amdgcn_wave_barrier();
-    epilogue_rows64<EPI>(acc, reinterpret_cast<char*>(&xch[0][0][0]), 0, n0, 0, 0, lane, M, ep);
+    epilogue_rows64<EPI>(acc, reinterpret_cast<char*>(&xch[0][0][0]), m0, n0, 0, 0, lane, M, ep);
   } else {
     float rs4[4];
-    load_row_scales(ep, 0, r16, M, rs4);
-    epilogue<EPI, 4>(acc, 0, n0, 0, 0, r16, g, M, ep, rs4);
+    load_row_scales(ep, m0, r16, M, rs4);
+    epilogue<EPI, 4>(acc, m0, n0, 0, 0, r16, g, M, ep, rs4);
   }
 }
 
 template <int EPI>
 int launch_skinny(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
-  if (M < 1 || M > 64 || N % 64 || K % 32) return GRAM_E_ARG;
-  const dim3 grid(N / 64), block(256);
+  if (M < 1 || N % 64 || K % 32 || (M + 63) / 64 > 65535) return GRAM_E_ARG;
+  const dim3 grid(N / 64, (M + 63) / 64), block(256);
   if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
   else if (M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
   else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
@@ -1789,7 +1789,8 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
   gram_prof::Scope prof(GRAM_K_GEMM, st, 2.0 * M * N * K);
   if constexpr (EPI != GRAM_EPI_KV_BANK) {
     static const int use_skinny = getenv("GRAM_GEMM_SKINNY") ? atoi(getenv("GRAM_GEMM_SKINNY")) : 1;  // A/B hook
-    if (g_force_variant == V_SKINNY || (g_force_variant < 0 && use_skinny && M <= 64 && N % 64 == 0 && K % 32 == 0))
+    static const int skinny_max_m = getenv("GRAM_GEMM_SKINNY_MAXM") ? atoi(getenv("GRAM_GEMM_SKINNY_MAXM")) : 64;  // A/B hook
+    if (g_force_variant == V_SKINNY || (g_force_variant < 0 && use_skinny && M <= skinny_max_m && N % 64 == 0 && K % 32 == 0))
       return launch_skinny<EPI>(A, W, M, N, K, lda, ep, st);
   }
   if constexpr (EPI == GRAM_EPI_F32_LSE) {  // 64-column wave tiles only: the ping-pong kernel (partials only) or the 128-row kernels

@@ -101,7 +101,7 @@ def test_gemm_persistent_variants(G, M, N, K):
         assert torch.equal(outs[8][key], outs[22][key]), key
 
 
-@pytest.mark.parametrize("M", [1, 16, 20, 33, 64])
+@pytest.mark.parametrize("M", [1, 16, 20, 33, 64, 100, 257])
 @pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (768, 3072), (1408, 512)])
 def test_gemm_skinny_matches_tiled(G, M, N, K):
     """The M <= 64 kernel (variant 30: one 16-column n-tile per wave over the whole K, operands straight from global
