@@ -231,22 +231,52 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
     __syncthreads();
   }
   if (!isdone) {
-    // bitonic sort, descending
-    for (int kk = 2; kk <= NC; kk <<= 1) {
-      for (int j = kk >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < NC; i += 256) {
-          const int ixj = i ^ j;
-          if (ixj > i) {
-            const unsigned long long a = keys[i], c = keys[ixj];
-            const bool desc = (i & kk) == 0;
-            if (desc ? (a < c) : (a > c)) {
-              keys[i] = c;
-              keys[ixj] = a;
-            }
+    // Only the best 2K candidates are looked at (topk(2K) in beam_search), in descending order: a bitonic TOP-P
+    // selection, P = the power of two >= 2K.  Sort every P-block (directions alternating, as in a full bitonic sort
+    // stopped at stage P), then halve the array round by round: a descending block followed by an ascending one is a
+    // bitonic sequence, so the elementwise maxima of the pair are a bitonic block that holds the pair's P largest keys;
+    // re-sort it (log2 P merge stages) and go on until one block is left.  ~3x fewer compare-exchanges than sorting
+    // all NC <= 16 384 keys; keys are unique (flat index in the low word), so the result is the full sort's prefix.
+    int P = 64;
+    while (P < 2 * K) P <<= 1;
+    const int top = NC < P ? NC : P;
+    auto stage = [&](int n, int kk, int j) {
+      for (int i = tid; i < n; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], c = keys[ixj];
+          const bool desc = (i & kk) == 0;
+          if (desc ? (a < c) : (a > c)) {
+            keys[i] = c;
+            keys[ixj] = a;
           }
         }
-        __syncthreads();
       }
+      __syncthreads();
+    };
+    for (int kk = 2; kk <= top; kk <<= 1)
+      for (int j = kk >> 1; j > 0; j >>= 1) stage(NC, kk, j);
+    for (int n = NC; n > P; n >>= 1) {
+      // blocks (2q, 2q+1) -> block q of the half-size array; every thread reads its pairs before anyone writes
+      const int half = n >> 1;
+      unsigned long long mx[32];  // half / 256 <= 8192 / 256 (K * max_fanout <= 16 384); statically indexed: stays in registers
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        const int o = tid + c * 256;
+        if (o < half) {
+          const int q = o / P, i = o - q * P;
+          const unsigned long long a = keys[(2 * q) * P + i], b2 = keys[(2 * q + 1) * P + i];
+          mx[c] = a > b2 ? a : b2;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        const int o = tid + c * 256;
+        if (o < half) keys[o] = mx[c];
+      }
+      __syncthreads();
+      for (int j = P >> 1; j > 0; j >>= 1) stage(half, P, j);  // bitonic blocks -> sorted, directions alternating again
     }
   }
 
