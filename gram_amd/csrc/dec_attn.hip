@@ -33,7 +33,7 @@ struct StepRegs {
   uint2 mk;
 };
 
-template <int NT>
+template <int NT, bool LIVE>  // LIVE: live-row step (gram_live_rows_t); a separate instantiation keeps the common kernel's code as it was
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
     const bf16* __restrict__ q, const bf16* __restrict__ kbank, const bf16* __restrict__ vtbank,
     const uint8_t* __restrict__ mask, bf16* __restrict__ out, int K, int H, int S, const int32_t* __restrict__ users,
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
 
   // live-row step (users != NULL): workgroup y serves user users[y]; q/out rows are the compact rows rowpos[b*K + beam]
   // (-1 = beam not live: zero query, nothing stored)
-  const int h = blockIdx.x, b = users ? users[blockIdx.y] : blockIdx.y;
+  const int h = blockIdx.x, b = LIVE ? users[blockIdx.y] : blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int inner = H * 64;
@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
   for (int nt = 0; nt < NT; ++nt) {
     const int beam = 16 * nt + c;
     int qrow = beam < K ? b * K + beam : -1;
-    if (rowpos && qrow >= 0) qrow = rowpos[qrow];
+    if constexpr (LIVE) {
+      if (qrow >= 0) qrow = rowpos[qrow];
+    }
 #pragma unroll
     for (int kd = 0; kd < 2; ++kd)
       qf[nt][kd] = qrow >= 0 ? ld_global_b128(q + (size_t)qrow * inner + h * 64 + 32 * kd + 8 * g) : zero_bf16x8();
@@ -234,8 +236,12 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void cross_attn_kernel(
     bf16x4 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = (bf16)(acc[e] * inv);
-    const int orow = rowpos ? rowpos[b * K + beam] : b * K + beam;
-    if (orow >= 0) *reinterpret_cast<bf16x4*>(out + (size_t)orow * inner + h * 64 + d4) = r;
+    if constexpr (LIVE) {
+      const int orow = rowpos[b * K + beam];
+      if (orow >= 0) *reinterpret_cast<bf16x4*>(out + (size_t)orow * inner + h * 64 + d4) = r;
+    } else {
+      *reinterpret_cast<bf16x4*>(out + ((size_t)b * K + beam) * inner + h * 64 + d4) = r;
+    }
   }
 }
 
@@ -245,13 +251,20 @@ int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* ma
   const size_t smem = (size_t)(2 * 4 * NT * 16 + 4 * NT * 16 * 64) * sizeof(float) + 16;
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_kernel<NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_kernel<NT, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_kernel<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(cross_attn_kernel<NT>, dim3(H, B), dim3(256), smem, st, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
-                     mask, (bf16*)out, K, H, S, users, rowpos);
+  if (users)
+    hipLaunchKernelGGL((cross_attn_kernel<NT, true>), dim3(H, B), dim3(256), smem, st, (const bf16*)q, (const bf16*)k,
+                       (const bf16*)vt, mask, (bf16*)out, K, H, S, users, rowpos);
+  else
+    hipLaunchKernelGGL((cross_attn_kernel<NT, false>), dim3(H, B), dim3(256), smem, st, (const bf16*)q, (const bf16*)k,
+                       (const bf16*)vt, mask, (bf16*)out, K, H, S, users, rowpos);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
