@@ -1164,6 +1164,22 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   char* const patch = smem + 8 * HT + (F32OUT ? wave * PATCH : TEND ? wave * 2048 : (wave & 3) * PATCH);
   const bool has_rs = !F32OUT && ep.ss_in != nullptr;  // ss_nblk == 0 (1/rms per row), checked by the launcher
 
+  // tile index -> (m-tile, n-tile column).  gm <= 1: n fastest.  gm > 1: groups of gm m-tiles, m fastest inside a group, so
+  // that the 32 tiles an XCD works on at a time cover gm m-tiles x 32/gm n-tiles (fewer distinct A + W panels per round).
+  const int gm = stagger >> 16;
+  stagger &= 0xffff;
+  auto decode = [&](int tile, int& mt, int& nr) {
+    if (gm <= 1) {
+      mt = tile / ntn;
+      nr = tile - mt * ntn;
+    } else {
+      const int per = gm * ntn, grp = tile / per, first = grp * gm;
+      const int gs = min(gm, (M + TB - 1) / TB - first);
+      const int rem = tile - grp * per;
+      nr = rem / gs;
+      mt = first + (rem - nr * gs);
+    }
+  };
   // DMA cursor = stream k-tile kk+2 (tile, kt) + per-lane byte offsets of this wave's 2 pieces of each half-tile type
   // (relative to the tile's first A row / W row, whose addresses c_A / c_W are wave-uniform and 64-bit)
   int c_tile = slot, c_kt = 0;
@@ -1179,7 +1195,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     }
   }
   auto set_offsets = [&]() {
-    const int mt = c_tile / ntn, nt = nt_of(c_tile - mt * ntn);
+    int mt, nr;
+    decode(c_tile, mt, nr);
+    const int nt = nt_of(nr);
     c_A = Ab + (size_t)mt * TB * lda * 2;
     c_W = Wb + (size_t)nt * TB * K * 2;
     const int mleft = M - 1 - mt * TB;  // last valid row, tile-relative
@@ -1548,7 +1566,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   zero_half(1);
   while (true) {
     {
-      const int mt = tile / ntn, nt = nt_of(tile - mt * ntn);
+      int mt, nr;
+      decode(tile, mt, nr);
+      const int nt = nt_of(nr);
       m0 = mt * TB;
       n0 = nt * TB;
     }
@@ -1737,8 +1757,13 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
+    // tile order (see decode() in the kernel): m-grouped where there are enough n-tiles for it to shrink an XCD's panel set
+    // measured (same box, whole path): n-fastest 6 684, groups of 4: 6 752, 6: 6 774, 8: 6 762 users/s
+    static const int gm_env = getenv("GRAM_GEMM_GROUPM") ? atoi(getenv("GRAM_GEMM_GROUPM")) : 6;  // A/B hook (0/1: n fastest)
+    const int ntn_ = ntiles / ((M + 255) / 256);
+    const int gm = ntn_ >= 8 && gm_env > 1 && gm_env < 256 ? gm_env : 0;
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda,
-                       ep, ntiles, g_stagger);
+                       ep, ntiles, (g_stagger & 0xffff) | (gm << 16));
     GRAM_CHECK_LAUNCH();
     return 0;
   }
