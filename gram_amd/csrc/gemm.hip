@@ -35,7 +35,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
-enum { V_REG2 = 0, V_DMA = 1, V_DMA2 = 2, V_DMA_M256 = 3, V_DMA2_M256 = 4, V_DMA2_256SQ = 5, V_DMA_256SQ = 6, V_RING = 7, V_IL = 8, V_PP = 22 };
+enum { V_DMA_M64 = 31, V_REG2 = 0, V_DMA = 1, V_DMA2 = 2, V_DMA_M256 = 3, V_DMA2_M256 = 4, V_DMA2_256SQ = 5, V_DMA_256SQ = 6, V_RING = 7, V_IL = 8, V_PP = 22 };
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
 int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain), see gemm_il_kernel
 
@@ -1783,6 +1783,9 @@ int pick_variant(int M, int N, int K) {
   // already wins at 480 tiles (M = 40960, N = 768: 230 us vs 277 us for the 128x128 variant)
   if (N % 256 == 0 && M >= 32768 && (tiles256 >= 2048 || K >= 2048)) return big;
   if (tiles256 >= 2048) return V_DMA_M256;
+  // few 128 x 128 tiles (a batch of 4 .. ~100 users in the decoder): 64-row tiles double the workgroups that pull the weights
+  static const int m64_max = getenv("GRAM_GEMM_M64_MAXTILES") ? atoi(getenv("GRAM_GEMM_M64_MAXTILES")) : 256;  // A/B hook; measured +1-2 % at B = 8 .. 256
+  if ((long)((M + 127) / 128) * (N / BN) < m64_max) return V_DMA_M64;
   return V_DMA;
 }
 
@@ -1824,8 +1827,10 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
       const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
       if (r != GRAM_E_ARG) return r;
     }
-    return pick_variant(M, N, K) == V_DMA ? launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st)
-                                          : launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, st);
+    const int pv = pick_variant(M, N, K);
+    return pv == V_DMA_M64 ? launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, st)
+           : pv == V_DMA   ? launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st)
+                           : launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, st);
   } else {
   if constexpr (EPI == GRAM_EPI_F32_ADD) {  // big-M residual GEMMs: the ping-pong kernel with its tile-end epilogue, whatever N and K
     static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
@@ -1836,6 +1841,7 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
   }
   switch (pick_variant(M, N, K)) {
     case V_DMA: return launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st);
+    case V_DMA_M64: return launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, st);
     case V_DMA2: return launch_dma<EPI, 2, 2>(A, W, M, N, K, lda, ep, st);
     case V_DMA_M256: return launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, st);
     case V_DMA2_M256: return launch_dma<EPI, 4, 2>(A, W, M, N, K, lda, ep, st);

@@ -158,6 +158,43 @@ def test_gemm_skinny_matches_tiled(G, M, N, K):
         assert torch.equal(outs[1][key], outs[30][key]), key
 
 
+@pytest.mark.parametrize("M,N,K", [(100, 768, 768), (1280, 2304, 768), (700, 768, 3072)])
+def test_gemm_64_row_tiles_match_128(G, M, N, K):
+    """Variant 31 (the 128-row kernel's template at 64 x 128 tiles) against variant 1, bit for bit."""
+    import ctypes as ct
+
+    from gram_amd import _lib
+    L_ = G.lib()
+    A, W = G.bf(_r(M, K, seed=31)), G.bf(_r(N, K, seed=32, scale=K ** -0.5))
+    ssin = (torch.rand(M, K // 64, generator=torch.Generator().manual_seed(33)) * 64 + 1).to(G.DEV)
+    base = _r(M, N, seed=34).to(G.DEV)
+    outs = {}
+    try:
+        for v in (1, 31):
+            L_.gram_debug_set_gemm_variant(v)
+            o = {}
+            y = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+            cons = _lib.NormFusion(None, None, ssin.data_ptr(), K // 64, K, 1e-6)
+            _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(y), M, N, K, K, N, _lib.EPI_BF16_RELU, None, ct.byref(cons), G.stream()), "consumer")
+            o["relu"] = y
+            x = base.clone()
+            xb = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+            ss = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=G.DEV)
+            prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
+            _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(x), M, N, K, K, N, _lib.EPI_F32_ADD, None, ct.byref(prod), G.stream()), "producer")
+            o["add"], o["xb"], o["ss"] = x, xb, ss
+            part = torch.full((M, N // 64, 2), float("nan"), dtype=torch.float32, device=G.DEV)
+            _lib.check(L_.gram_gemm_bf16_lse(G.p(A), G.p(W), None, G.p(part), M, N, K, K, N, G.stream()), "lse")
+            o["lse"] = part
+            torch.cuda.synchronize()
+            outs[v] = o
+    finally:
+        L_.gram_debug_set_gemm_variant(-1)
+    assert torch.allclose(outs[31]["add"], base + A.float() @ W.float().T, atol=2e-3, rtol=1e-4)
+    for key in outs[1]:
+        assert torch.equal(outs[1][key], outs[31][key]), key
+
+
 def test_gemm_asymmetric_identity(G):
     """A = I with an asymmetric W catches a transposed / row-col swapped fragment mapping."""
     from gram_amd import _lib
