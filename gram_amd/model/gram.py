@@ -130,7 +130,8 @@ class GRAM(nn.Module):
         self._packed = None  # (device, version, handle, keepalive)
         self._version = 0
         self._workspace = None
-        self._tries: Dict[int, FlatTrie] = {}
+        self._tries: Dict[int, tuple] = {}  # id(trie) -> (trie, FlatTrie)
+        self._precision = os.environ.get("GRAM_PRECISION", "bf16")
         self._pcache = None  # passage cache: dict(x, canon, keys, perm) on the device
 
     # ------------------------------------------------------------------ weights
@@ -172,6 +173,17 @@ class GRAM(nn.Module):
                 k = "encoder." + k
             remapped[k] = v
         return self.load_state_dict(remapped, strict=False)
+
+    PRECISIONS = ("bf16",)
+
+    def set_precision(self, mode: str) -> None:
+        """Arithmetic of the GEMM / attention operands (accumulation, residual stream, softmax and scores are fp32 in
+        every mode).  The packed weights depend on it, so changing it re-packs on the next ``generate``."""
+        if mode not in self.PRECISIONS:
+            raise ValueError(f"unknown precision {mode!r}; choose from {self.PRECISIONS}")
+        if mode != self._precision:
+            self._precision = mode
+            self._invalidate()
 
     def _invalidate(self) -> None:
         self._version += 1
@@ -322,13 +334,15 @@ class GRAM(nn.Module):
         return None
 
     def _flat_trie(self, fn: Callable) -> FlatTrie:
+        """Device CSR of the closure's Trie, cached per Trie OBJECT.  The entry holds a strong reference to its
+        source, so the id cannot be recycled by a later Trie while the entry is alive (the runner builds a fresh
+        Trie per evaluation), and the item count guards against in-place ``add`` calls."""
         trie = self._closure_trie(fn)
-        key = id(trie)
-        cached = self._tries.get(key)
-        if cached is None or cached.n_sequences != len(trie):
-            cached = FlatTrie(trie)
-            self._tries = {key: cached}  # one live Trie per eval; drop stale ones
-        return cached
+        cached = self._tries.get(id(trie))
+        if cached is None or cached[0] is not trie or cached[1].n_sequences != len(trie):
+            cached = (trie, FlatTrie(trie))
+            self._tries = {id(trie): cached}  # one live Trie per eval; drop stale ones
+        return cached[1]
 
     # ------------------------------------------------------------------ which passages the encoder runs on
     _CACHE_L = _lib.GRAM_MAX_PASSAGE_LEN

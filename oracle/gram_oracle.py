@@ -155,8 +155,8 @@ def relative_position_bucket(rel: Tensor, bidirectional: bool, num_buckets: int,
 
 def position_bias(table: Tensor, q_len: int, k_len: int, bidirectional: bool, cfg: OracleConfig) -> Tensor:
     """T5Attention.compute_bias, gram_t5_modeling.py:452-477 -> (1, H, q_len, k_len)."""
-    ctx = torch.arange(q_len, dtype=torch.long)[:, None]
-    mem = torch.arange(k_len, dtype=torch.long)[None, :]
+    ctx = torch.arange(q_len, dtype=torch.long, device=table.device)[:, None]
+    mem = torch.arange(k_len, dtype=torch.long, device=table.device)[None, :]
     bucket = relative_position_bucket(
         mem - ctx, bidirectional, cfg.relative_attention_num_buckets, cfg.relative_attention_max_distance
     )
@@ -212,7 +212,7 @@ def late_fusion(sd: Dict[str, Tensor], cfg: OracleConfig, hidden: Tensor, B: int
     P, L, d = hidden.shape
     assert P == B * N
     if cfg.use_position_embedding:
-        pos = sd["position_embedding.weight"][torch.arange(N)]  # (N,d)
+        pos = sd["position_embedding.weight"][torch.arange(N, device=hidden.device)]  # (N,d)
         hidden = hidden + pos.repeat(B, 1).view(B * N, 1, d)
     return hidden.view(B, N * L, d)
 
@@ -430,17 +430,25 @@ def beam_search(
     while True:
         cur_len = input_ids.shape[1]
         logits = step_fn(input_ids[:, -1])
+        dev = logits.device  # the floating-point stack may sit on an accelerator (tests at population scale); the
+        #                      bookkeeping below always runs on the host, on the top-2K candidates only
         logp = torch.log_softmax(logits.float(), dim=-1)
         V = logp.shape[-1]
         if prefix_fn is not None:  # PrefixConstrainedLogitsProcessor
             mask = torch.full_like(logp, -math.inf)
+            rows: List[int] = []
+            cols: List[int] = []
             for b in range(B):
                 for k in range(K):
-                    allowed = prefix_fn(b, input_ids[b * K + k])
-                    mask[b * K + k, allowed] = 0  # empty list -> whole row -inf (4.26: no raise)
+                    allowed = prefix_fn(b, input_ids[b * K + k])  # empty list -> whole row -inf (4.26: no raise)
+                    rows.extend([b * K + k] * len(allowed))
+                    cols.extend(int(a) for a in allowed)
+            if rows:
+                mask[torch.tensor(rows, dtype=torch.long, device=dev), torch.tensor(cols, dtype=torch.long, device=dev)] = 0
             logp = logp + mask
-        scores = (logp + beam_scores[:, None]).view(B, K * V)
+        scores = (logp + beam_scores.to(dev)[:, None]).view(B, K * V)
         next_scores, flat = topk_candidates(scores, 2 * K)
+        next_scores, flat = next_scores.cpu(), flat.cpu()
         next_indices = torch.div(flat, V, rounding_mode="floor")
         next_tokens = flat % V
         if trace is not None:
@@ -563,6 +571,7 @@ def generate(
     shares the bank across a user's beams.  Both give the same results up to fp32 rounding."""
     B, N, L = input_ids.shape
     K = num_beams
+    dev = input_ids.device  # cpu everywhere except the population-scale tests, which run this same code on the GPU in fp32
     with torch.no_grad():
         enc = encode_fused(sd, cfg, input_ids, attention_mask)  # (B,S,d)
         mask2 = attention_mask.reshape(B, N * L).to(torch.float32)
@@ -573,12 +582,12 @@ def generate(
         else:
             st = DecodeState(cross=cross_kv(sd, cfg, enc), enc_mask_ext=ext, rows_per_bank=K)
         if K == 1:  # HF dispatches num_beams == 1 to greedy_search
-            seqs = greedy_search(lambda tok: decoder_step(sd, cfg, tok, st), B, max_length, prefix_allowed_tokens_fn,
+            seqs = greedy_search(lambda tok: decoder_step(sd, cfg, tok.to(dev), st).cpu(), B, max_length, prefix_allowed_tokens_fn,
                                  cfg.pad_token_id, cfg.eos_token_id, cfg.decoder_start_token_id)
             return {"sequences": seqs, "sequences_scores": None, "encoder_last_hidden_state": enc}
         seqs, scores = beam_search(
-            lambda tok: decoder_step(sd, cfg, tok, st),
-            st.reorder,
+            lambda tok: decoder_step(sd, cfg, tok.to(dev), st),
+            lambda beam_idx: st.reorder(beam_idx.to(dev)),
             B, K, max_length, prefix_allowed_tokens_fn, length_penalty, num_return_sequences,
             cfg.pad_token_id, cfg.eos_token_id, cfg.decoder_start_token_id, early_exit, trace,
         )

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Population-scale precision measurement of the HIP path against the fp32 reference arithmetic.
+
+TEST INFRASTRUCTURE (imports oracle/).  The north star asks for Recall@5 / NDCG@5 within 1e-4 of the reference,
+which computes in fp32 end to end (SURVEY.md "Facts").  The CPU oracle cannot score thousands of T5-base users
+(0.1 users/s), so this script runs THE SAME oracle code (oracle/gram_oracle.py, plain torch fp32 ops) with its
+tensors on the GPU -- rocBLAS fp32 GEMMs, fp32 softmax, the pinned HF-4.26 beam search on the host -- as the
+on-GPU fp32 reference, and compares ``gram_amd.GRAM.generate`` in each precision mode with it on identical weights
+and inputs:
+
+  * hit@5 / ndcg@5 / hit@10 / ndcg@10 of both sides with the gold item of user u placed at the reference's rank
+    u mod 10 (so every rank flip inside the top 10 moves a metric), and their absolute differences;
+  * rank flips: users whose gold item sits at a different rank; membership changes of the top-K;
+  * adjacent-pair order swaps as a function of the reference's score gap between the two items;
+  * max |score difference| over sequences both sides returned.
+
+    python tests/precision_population.py --users 4096 --chunk 256 --modes bf16 --out gpurun_out/precision.json
+
+``--sharpen F`` multiplies every attention q projection by F: at T5's random init the attention logits are ~N(0,1)
+and every query averages ~140 keys, which washes the encoder out of the scores (all users get nearly the same
+beams); F = 4 gives peaky attention (a few keys per query), i.e. scores that depend on the passages as a trained
+model's do.  Both populations are reported.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GAP_EDGES = [0.0, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, float("inf")]
+METRICS = ["hit@5", "ndcg@5", "hit@10", "ndcg@10"]
+
+
+def _strip(row):
+    return tuple(int(t) for t in row if int(t) not in (0, 1))
+
+
+def build(backbone, seed, sharpen, dev):
+    import gram_amd
+    from oracle import gram_oracle as O
+
+    if backbone == "tiny":
+        oc = O.OracleConfig(vocab_size=256, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2,
+                            max_item_num=5)
+    else:
+        oc = O.OracleConfig.named(backbone)
+    gc = gram_amd.T5Config(vocab_size=oc.vocab_size, d_model=oc.d_model, d_ff=oc.d_ff, num_layers=oc.num_layers,
+                           num_decoder_layers=oc.num_decoder_layers, num_heads=oc.num_heads, max_item_num=oc.max_item_num)
+    sd = O.init_state_dict(oc, seed)
+    if sharpen != 1.0:
+        for k in sd:
+            if k.endswith(".q.weight"):
+                sd[k] = sd[k] * sharpen
+    model = gram_amd.create_model("gram", gc)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    sd_dev = {}
+    seen = {}
+    for k, v in sd.items():  # keep the aliases aliased on the device
+        if id(v) not in seen:
+            seen[id(v)] = v.to(dev)
+        sd_dev[k] = seen[id(v)]
+    return oc, sd_dev, model
+
+
+def compare(ref_seqs, ref_scores, out_seqs, out_scores, B, K, user0, acc):
+    """Accumulate the statistics of one chunk into ``acc`` (see the module docstring)."""
+    from gram_amd.utils import evaluate as ev
+
+    opred = [_strip(s) for s in ref_seqs.tolist()]
+    dpred = [_strip(s) for s in out_seqs.tolist()]
+    osc, dsc = ref_scores.tolist(), out_scores.tolist()
+    gold = [opred[b * K + (user0 + b) % 10 % K] for b in range(B)]
+    orel = ev.rel_results(opred, gold, osc, K)
+    drel = ev.rel_results(dpred, gold, dsc, K)
+    acc["flips"] += int((ev.hit_ranks(orel) != ev.hit_ranks(drel)).sum())
+    acc["o_sum"] += ev.get_metrics_results(orel, METRICS)
+    acc["d_sum"] += ev.get_metrics_results(drel, METRICS)
+    acc["users"] += B
+    for b in range(B):
+        o_items, d_items = opred[b * K:(b + 1) * K], dpred[b * K:(b + 1) * K]
+        o_s, d_s = osc[b * K:(b + 1) * K], dsc[b * K:(b + 1) * K]
+        dpos = {it: i for i, it in enumerate(d_items)}
+        acc["membership_changes"] += sum(1 for it in o_items if it not in dpos)
+        acc["top1_same"] += int(o_items[0] == d_items[0])
+        acc["order_same"] += int(o_items == d_items)
+        for i, it in enumerate(o_items):
+            if it in dpos:
+                acc["max_score_dev"] = max(acc["max_score_dev"], abs(o_s[i] - d_s[dpos[it]]))
+                acc["sum_score_dev"] += abs(o_s[i] - d_s[dpos[it]])
+                acc["n_score_dev"] += 1
+        for r in range(min(K - 1, 10)):  # adjacent pairs of the reference's top 11
+            a, c = o_items[r], o_items[r + 1]
+            gap = o_s[r] - o_s[r + 1]
+            bucket = next(i for i in range(len(GAP_EDGES) - 1) if GAP_EDGES[i] <= gap < GAP_EDGES[i + 1])
+            acc["pairs"][bucket] += 1
+            if a in dpos and c in dpos:
+                acc["swaps"][bucket] += int(dpos[a] > dpos[c])
+            else:
+                acc["swaps"][bucket] += 1
+
+
+def new_acc():
+    return dict(flips=0, o_sum=np.zeros(len(METRICS)), d_sum=np.zeros(len(METRICS)), users=0, membership_changes=0, top1_same=0,
+                order_same=0, max_score_dev=0.0, sum_score_dev=0.0, n_score_dev=0, pairs=[0] * (len(GAP_EDGES) - 1),
+                swaps=[0] * (len(GAP_EDGES) - 1))
+
+
+def summarise(acc):
+    n = max(acc["users"], 1)
+    delta = np.abs(acc["o_sum"] - acc["d_sum"]) / n
+    return {
+        "users": acc["users"],
+        "rank_flips": acc["flips"],
+        "metrics_reference": dict(zip(METRICS, (acc["o_sum"] / n).round(6).tolist())),
+        "metrics_device": dict(zip(METRICS, (acc["d_sum"] / n).round(6).tolist())),
+        "abs_delta": dict(zip(METRICS, [float(f"{x:.3e}") for x in delta])),
+        "top1_same": acc["top1_same"], "topK_order_same": acc["order_same"], "membership_changes": acc["membership_changes"],
+        "max_abs_score_dev": acc["max_score_dev"], "mean_abs_score_dev": acc["sum_score_dev"] / max(acc["n_score_dev"], 1),
+        "adjacent_pair_swaps_by_reference_gap": [
+            {"gap": f"[{GAP_EDGES[i]:g}, {GAP_EDGES[i + 1]:g})", "pairs": acc["pairs"][i], "swapped": acc["swaps"][i]}
+            for i in range(len(GAP_EDGES) - 1)],
+    }
+
+
+def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("bf16",), seed=2023, sharpen=1.0, N=3, L=128, K=20,
+        dev="cuda:0", log=print, n_items=0):
+    from gram_amd.utils import generation_trie as gt
+    from oracle import gram_oracle as O
+
+    oc, sd, model = build(backbone, seed, sharpen, dev)
+    if backbone == "tiny":
+        g0 = torch.Generator().manual_seed(5)
+        cands = sorted({tuple([0] + torch.randint(2, 60, (3,), generator=g0).tolist() + [1]) for _ in range(n_items or 400)})
+        cands = [list(c) for c in cands]
+        vmax = 256
+    else:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "tries.npz"))
+        cands = [[int(x) for x in row if x >= 0] for row in z[f"{dataset}_cands"]]
+        vmax = 32100
+    max_length = max(len(c) for c in cands)
+    dfn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
+    ofn = O.prefix_allowed_tokens_fn(O.Trie(cands))
+    accs = {m: new_acc() for m in modes}
+    t_ref = t_dev = 0.0
+    g = torch.Generator().manual_seed(seed + 1)
+    for u0 in range(0, users, chunk):
+        B = min(chunk, users - u0)
+        ids = torch.randint(2, vmax, (B, N, L), generator=g)
+        ids[:, :, -1] = 1
+        mask = torch.ones(B, N, L, dtype=torch.bool)
+        ids_d, mask_d = ids.to(dev), mask.to(dev)
+        t0 = time.perf_counter()
+        ref = O.generate(sd, oc, ids_d, mask_d, max_length, ofn, K, K, 1.0)
+        torch.cuda.synchronize()
+        t_ref += time.perf_counter() - t0
+        for m in modes:
+            model.set_precision(m)
+            t0 = time.perf_counter()
+            out = model.generate(input_ids=ids_d, attention_mask=mask_d, max_length=max_length, prefix_allowed_tokens_fn=dfn,
+                                 num_beams=K, num_return_sequences=K, length_penalty=1.0)
+            torch.cuda.synchronize()
+            t_dev += time.perf_counter() - t0
+            compare(ref["sequences"].cpu(), ref["sequences_scores"].cpu(), out["sequences"].cpu(), out["sequences_scores"].cpu(),
+                    B, K, u0, accs[m])
+        log(f"[precision] users {u0 + B}/{users}  ref {t_ref:.0f}s dev {t_dev:.0f}s  " +
+            "  ".join(f"{m}: flips {a['flips']} max|ds| {a['max_score_dev']:.2e}" for m, a in accs.items()))
+    return {
+        "population": {"backbone": backbone, "dataset": dataset, "items": len(cands), "users": users, "N": N, "L": L, "K": K,
+                       "seed": seed, "q_sharpen": sharpen, "gold_rank": "reference rank (user index mod 10)",
+                       "reference": "oracle/gram_oracle.py run with torch fp32 tensors on the GPU (rocBLAS fp32), HF-4.26 search on the host"},
+        "modes": {m: summarise(a) for m, a in accs.items()},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=4096)
+    ap.add_argument("--chunk", type=int, default=256)
+    ap.add_argument("--backbone", default="t5-base")
+    ap.add_argument("--dataset", default="Beauty")
+    ap.add_argument("--modes", default="bf16")
+    ap.add_argument("--seed", type=int, default=2023)
+    ap.add_argument("--sharpen", type=float, default=1.0)
+    ap.add_argument("--beams", type=int, default=20)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    res = run(a.users, a.chunk, a.backbone, a.dataset, tuple(a.modes.split(",")), a.seed, a.sharpen, K=a.beams)
+    txt = json.dumps(res, indent=1)
+    print(txt)
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        with open(a.out, "w") as f:
+            f.write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()

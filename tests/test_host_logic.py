@@ -187,3 +187,23 @@ def test_dataset_and_indexing_match_reference_fixtures(golden_dir, monkeypatch):
         indexing.gram_indexing("dataset_fixture", "Beauty", None, None, args=SimpleNamespace(**dict(a, top_k_similar_item=0)))
     with pytest.raises(AssertionError):
         TestDatasetGRAM(SimpleNamespace(**a), "Beauty", "rating", None, None)
+
+
+def test_flat_trie_cache_tracks_the_trie_object():
+    """Two same-sized Tries built one after the other (CPython recycles the address of the first) must not share a
+    cached CSR: the cache entry pins its source Trie and is keyed by object identity."""
+    cfg = gram_amd.T5Config(vocab_size=256, d_model=128, d_ff=256, num_layers=1, num_decoder_layers=1, num_heads=2, max_item_num=3)
+    m = gram_amd.create_model("gram", cfg)
+    seen = []
+    for base in (10, 20, 30, 40):
+        trie = gt.Trie([[0, base + i, base + 5 + i, 1] for i in range(4)])
+        flat = m._flat_trie(gt.prefix_allowed_tokens_fn(trie))
+        seen.append(sorted(int(t) for t in flat.child_tok))
+        del trie, flat
+    assert all(seen[i] != seen[j] for i in range(4) for j in range(i))
+    trie = gt.Trie([[0, 2, 3, 1]])
+    fn = gt.prefix_allowed_tokens_fn(trie)
+    a = m._flat_trie(fn)
+    assert m._flat_trie(fn) is a          # same object: cached
+    trie.add([0, 2, 4, 1])
+    assert m._flat_trie(fn) is not a      # grown in place: rebuilt
