@@ -11,6 +11,11 @@ of B synthetic users already resident in HBM (random-init weights of the exact a
 uniform token ids, all-valid masks: there is no network for checkpoints or tokenisers).  Users are
 independent, so N GPUs run N disjoint batches (weak scaling, no data-path collective).
 
+``--gpus N`` without a launcher starts the N ranks itself (children spawned BEFORE this process touches the GPU, one per
+device, RCCL over 127.0.0.1); under torchrun (RANK/WORLD_SIZE in the environment) it is one of the ranks.  With N > 1 the
+timed region ends with the eval's real exchange: every rank's hit ranks (position of a synthetic gold item in its top-K)
+in ONE all_gather_into_tensor over RCCL, cross-checked by the reference's all_reduce(SUM) of metric sums.
+
 One JSON line is printed by rank 0.  Besides the contract keys it carries
   roofline      the dominant kernel by summed device time, measured live with HIP events on the
                 launch stream over the timed region (gram_prof_* in libgram_hip.so)
@@ -36,6 +41,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+# The arithmetic the headline is timed in: the cheapest mode for which tests/test_gpu_precision.py asserts
+# |dRecall@5|, |dNDCG@5| <= 1e-4 against the fp32 reference on 4 096 T5-base users (profiles/r02_precision_*.json).
+DEFAULT_PRECISION = "bf16x3"
+PIECES = {"bf16": 1, "bf16x3": 2, "bf16x6": 3}
+NPROD = {"bf16": 1, "bf16x3": 3, "bf16x6": 6}
 
 
 def parse():
@@ -49,7 +59,12 @@ def parse():
     ap.add_argument("--passages", type=int, default=3)
     ap.add_argument("--passage-len", type=int, default=128)
     ap.add_argument("--beams", type=int, default=20)
-    ap.add_argument("--cpu-users", type=int, default=2, help="users in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-users", type=int, default=8, help="users in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=sorted(PIECES),
+                    help="operand arithmetic (gram_split_t): bf16 = 8 significant bits; bf16x3 / bf16x6 = 2 / 3 bf16 pieces per "
+                         "value, 3 / 6 MFMA products per product (fp32-class); accumulation, softmax and scores are fp32 in all")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements of the N = 1 run (all-rows decode, B = 1 latency, the other precision modes)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--ragged", action="store_true",
                     help="realistic batch: passage counts drawn from the dataset's histogram (padded to --passages), valid "
@@ -70,8 +85,31 @@ def _strip(row):
     return tuple(row)
 
 
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N ranks of this script (one per device) and relay rank 0's JSON line.  Runs before
+    anything here touches the GPU; the parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -99,6 +137,7 @@ def main():
     model = gram_amd.create_model("gram", cfg)
     state = {k: v.detach().clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_users > 0 and world == 1) else None
     model = model.to(dev).eval()
+    model.set_precision(args.precision)
 
     z = np.load(os.path.join(ROOT, "tests", "golden", "tries.npz"))
     cands = [[int(x) for x in row if x >= 0] for row in z[f"{args.dataset}_cands"]]
@@ -155,6 +194,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # synthetic gold item per user (uniform over the candidates, seeded per rank) -> hit rank in the returned top-K
+    gold_idx = torch.randint(0, len(cands), (B,), generator=g)
+    gold = torch.zeros(B, max_length, dtype=torch.int64)
+    for b, gi in enumerate(gold_idx.tolist()):
+        gold[b, : len(cands[gi])] = torch.tensor(cands[gi])
+    gold_d = gold.to(dev)
+
+    def hit_ranks(out):
+        seq = out["sequences"]
+        pad = torch.zeros(B * K, max_length, dtype=torch.int64, device=dev)
+        pad[:, : seq.shape[1]] = seq
+        same = (pad.view(B, K, max_length) == gold_d[:, None, :]).all(-1)  # (B, K); sequences are score-sorted
+        first = torch.where(same.any(1), same.float().argmax(1), torch.full((B,), -1.0, device=dev))
+        return first.to(torch.int16).cpu().numpy()
+
     for _ in range(args.warmup):
         out = step()
     kinds = {"gemm": _lib.K_GEMM, "enc_attn": _lib.K_ENC_ATTN, "cross_attn": _lib.K_CROSS_ATTN,
@@ -167,6 +221,22 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    exchange = None
+    if distributed:
+        # the eval's one exchange (distributed_runner_gram.py:832-838): all ranks' hit ranks in one fixed-size all-gather
+        # over RCCL/xGMI, cross-checked by the reference's all_reduce(SUM) of the metric sums
+        from gram_amd.runner import all_gather_hit_ranks
+        from gram_amd.utils import evaluate as ev
+        cdev = dev if args.backend == "nccl" else torch.device("cpu")
+        mine = hit_ranks(out)
+        allr = all_gather_hit_ranks(mine, cdev)
+        names = ["hit@5", "hit@10", "ndcg@5", "ndcg@10"]
+        sums = ev.metrics_from_ranks(allr, names, K)
+        local = torch.tensor(ev.metrics_from_ranks(mine, names, K), dtype=torch.float64, device=cdev)
+        dist.all_reduce(local, op=dist.ReduceOp.SUM)
+        assert len(allr) == world * B and np.allclose(local.cpu().numpy(), sums), "all-gather and all-reduce disagree"
+        exchange = {"collective": f"all_gather_into_tensor of {world} x {B} int32 hit ranks + all_reduce(SUM) cross-check, backend {args.backend}",
+                    "users_gathered": int(len(allr)), "metrics_vs_synthetic_gold": dict(zip(names, (sums / len(allr)).round(6).tolist()))}
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
@@ -199,7 +269,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": args.precision,
         "data": "synthetic",
         "config": {
             "workload": f"{args.dataset} Trie ({len(cands)} items, T={max_length - 1}), {args.backbone}, "
@@ -208,8 +278,15 @@ def main():
                            f"(NOT the headline configuration)" if item_cache else ""),
             "ragged": bool(args.ragged), "item_cache": item_cache,
             "live_row_compaction": os.environ.get("GRAM_LIVE_ROWS", "1") != "0", "users_per_step_per_gpu": B, "parallelism": f"dp{world} (users sharded, no data-path collective)",
-            "precision": "bf16 operands / fp32 accumulate, fp32 residual stream, softmax and scores",
+            "precision": {"bf16": "bf16 operands / fp32 accumulate, fp32 residual stream, softmax and scores",
+                          "bf16x3": "every operand as 2 bf16 pieces, every product as 3 bf16 MFMA products (~2^-18 relative), fp32 "
+                                    "accumulate / residual stream / softmax / scores; bank and activations stored as hi + lo pieces",
+                          "bf16x6": "every operand as 3 bf16 pieces, every product as 6 bf16 MFMA products (fp32-class), fp32 "
+                                    "accumulate / residual stream / softmax / scores"}[args.precision],
+            "parity": "tests/test_gpu_precision.py: |dRecall@5|, |dNDCG@5| <= 1e-4 vs the fp32 reference arithmetic on 4 096 users in "
+                      "this mode; profiles/r02_precision_*.json",
         },
+        "exchange": exchange,
         "output_check": {"sequences_shape": list(out["sequences"].shape),
                          "all_in_trie": bool(all(_strip(s) in {tuple(c) for c in cands}
                                                  for s in out["sequences"][: 2 * K].cpu().tolist()))},

@@ -18,6 +18,12 @@ GRAM_MAX_PASSAGE_LEN = 128
 EPI_BF16, EPI_BF16_RELU, EPI_F32_ADD, EPI_F32, EPI_KV_BANK = range(5)
 K_GEMM, K_ENC_ATTN, K_CROSS_ATTN, K_DEC_SELF_ATTN, K_ROWOPS, K_LSE, K_BEAM = range(7)
 E_ARG, E_WORKSPACE, E_BEAM = -1, -2, -3
+ABI_VERSION = 3
+# split-bf16 precision modes (gram_hip.h: GRAM_SPLIT_*): bf16 pieces per value -> products, and the (A piece, W piece) of each
+MAX_PIECES = 3
+SPLIT_NPROD = (0, 1, 3, 6)
+SPLIT_A_PIECE = ((), (0,), (0, 1, 0), (0, 2, 1, 1, 0, 0))
+SPLIT_W_PIECE = ((), (0,), (1, 0, 0), (2, 0, 1, 0, 1, 0))
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -45,6 +51,10 @@ class BeamState(C.Structure):
                 ("n_hyps", vp), ("hyp_score", vp), ("worst", vp), ("hyp_len", vp), ("hyp_tok", vp), ("error", vp)]
 
 
+class Split(C.Structure):
+    _fields_ = [("pieces", i32), ("a_pstride", i64), ("c_pstride", i64), ("xb_pstride", i64), ("bank_pstride", i64)]
+
+
 class NormFusion(C.Structure):
     _fields_ = [("xb_out", vp), ("ss_out", vp), ("ss_in", vp), ("nblk_in", i32), ("d", i32), ("eps", f32)]
 
@@ -67,6 +77,7 @@ class ModelDesc(C.Structure):
         ("dec_ln2", C.POINTER(vp)), ("dec_wq_x", C.POINTER(vp)), ("dec_wo_x", C.POINTER(vp)),
         ("dec_ln3", C.POINTER(vp)), ("dec_wi", C.POINTER(vp)), ("dec_wo2", C.POINTER(vp)),
         ("dec_wkv_x_all", vp),
+        ("pieces", i32), ("lm_head_f32", vp),
     ]
 
 
@@ -98,6 +109,7 @@ SIGNATURES = {
     "gram_encode_fused": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, C.c_int, vp, vp]),
     "gram_decode_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
     "gram_debug_set_gemm_variant": (C.c_int, [C.c_int]),
+    "gram_debug_set_live_rows": (C.c_int, [C.c_int]),
     "gram_debug_stream_read": (C.c_int, [vp, C.c_size_t, vp, vp]),
     "gram_prof_enable": (C.c_int, [C.c_uint32, C.c_int]),
     "gram_prof_reset": (C.c_int, []),
@@ -111,6 +123,17 @@ SIGNATURES = {
     "gram_dec_self_attn_live": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
     "gram_cross_attn_decode_live": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "gram_beam_step_sparse_live": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), vp, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]),
+    "gram_gemm_bf16_split": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KVBank),
+                                       C.POINTER(NormFusion), C.POINTER(Split), vp]),
+    "gram_gemm_bf16_lse_split": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Split), vp]),
+    "gram_embed_ex_split": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, vp]),
+    "gram_rmsnorm_bf16_split": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, f32, f32, vp, C.c_int, C.c_int, vp, C.c_int, i64, vp]),
+    "gram_enc_self_attn_split": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64, vp]),
+    "gram_cross_attn_decode_split": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, i64, i64, i64, vp]),
+    "gram_dec_self_attn_split": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64,
+                                           i64, vp]),
+    "gram_beam_step_sparse_split": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int,
+                                              vp, C.c_int, i64, vp]),
     "gram_generate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.POINTER(Trie),
                                 vp, i64, vp, vp, C.POINTER(i32), vp]),
 }
@@ -133,7 +156,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.gram_abi_version() != 2:
+    if lib.gram_abi_version() != ABI_VERSION:
         raise ImportError("libgram_hip.so ABI version mismatch")
     _lib = lib
     return lib

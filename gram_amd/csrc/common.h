@@ -35,6 +35,12 @@ __device__ __forceinline__ bf16x8 zero_bf16x8() {
   return z;
 }
 
+// products of the split-bf16 modes (gram_hip.h: GRAM_SPLIT_A_PIECE / GRAM_SPLIT_W_PIECE), smallest first
+template <int S> struct SplitTab;
+template <> struct SplitTab<1> { static constexpr int NP = 1; static constexpr int A[6] = {0, 0, 0, 0, 0, 0}; static constexpr int B[6] = {0, 0, 0, 0, 0, 0}; };
+template <> struct SplitTab<2> { static constexpr int NP = 3; static constexpr int A[6] = {0, 1, 0, 0, 0, 0}; static constexpr int B[6] = {1, 0, 0, 0, 0, 0}; };
+template <> struct SplitTab<3> { static constexpr int NP = 6; static constexpr int A[6] = {0, 2, 1, 1, 0, 0}; static constexpr int B[6] = {2, 0, 1, 0, 1, 0}; };
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

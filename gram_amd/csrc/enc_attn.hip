@@ -19,14 +19,17 @@ namespace {
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int vtswz(int d, int key) { return d * 256 + ((((key >> 3) ^ (d & 15))) << 4) + (key & 7) * 2; }
 
-template <int NKS>  // L = 32 * NKS
+template <int NKS, int S>  // L = 32 * NKS; S = bf16 pieces per value (1: plain bf16; 2, 3: gram_split_t)
 __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bias,
-                                                       const uint8_t* __restrict__ mask, bf16* __restrict__ out, int H) {
+                                                       const uint8_t* __restrict__ mask, bf16* __restrict__ out, int H,
+                                                       long qkv_pstride, long out_pstride) {
   constexpr int L = 32 * NKS;
-  __shared__ __attribute__((aligned(16))) char ks[128 * 128];
-  __shared__ __attribute__((aligned(16))) char vts[64 * 256];
-  __shared__ float bias_s[256];
-  __shared__ float mask_s[128];
+  using T = SplitTab<S>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks = smem;                       // [S][128 * 128]
+  char* vts = smem + S * 128 * 128;      // [S][64 * 256]
+  float* bias_s = reinterpret_cast<float*>(smem + S * 2 * 128 * 128);  // [256]
+  float* mask_s = bias_s + 256;                                        // [128]
 
   const int h = blockIdx.x, p = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,21 +39,22 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
 
   // K and V rows -> LDS: all 2*NKS 16-byte loads of a thread go out first (written as load; store per iteration,
   // hipcc waits for each pair before issuing the next: NKS exposed HBM round trips per workgroup)
-  {
+#pragma unroll
+  for (int pc = 0; pc < S; ++pc) {
     bf16x8 kv[NKS], vv[NKS];
 #pragma unroll
     for (int it = 0; it < NKS; ++it) {
       const int i = tid + it * 256, row = i >> 3, c = i & 7;
-      const bf16* src = base + (size_t)row * rs + c * 8;
+      const bf16* src = base + pc * qkv_pstride + (size_t)row * rs + c * 8;
       kv[it] = ld_global_b128(src + inner);
       vv[it] = ld_global_b128(src + 2 * inner);
     }
 #pragma unroll
     for (int it = 0; it < NKS; ++it) {
       const int i = tid + it * 256, row = i >> 3, c = i & 7;
-      *reinterpret_cast<bf16x8*>(ks + kswz(row, c)) = kv[it];
+      *reinterpret_cast<bf16x8*>(ks + pc * 128 * 128 + kswz(row, c)) = kv[it];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(vts + vtswz(c * 8 + e, row)) = vv[it][e];
+      for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(vts + pc * 64 * 256 + vtswz(c * 8 + e, row)) = vv[it][e];
     }
   }
   if (tid < 255) bias_s[tid] = bias[h * 255 + tid];
@@ -61,11 +65,14 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
   if (q0 >= L) return;
   const int c = lane & 15, g = lane >> 4;
 
-  bf16x8 qf[2][2];
+  bf16x8 qf[S][2][2];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+  for (int pc = 0; pc < S; ++pc)
 #pragma unroll
-    for (int kd = 0; kd < 2; ++kd) qf[nt][kd] = ld_global_b128(base + (size_t)(q0 + 16 * nt + c) * rs + 32 * kd + 8 * g);
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int kd = 0; kd < 2; ++kd)
+        qf[pc][nt][kd] = ld_global_b128(base + pc * qkv_pstride + (size_t)(q0 + 16 * nt + c) * rs + 32 * kd + 8 * g);
 
   f32x4 s[NKS][2][2];
 #pragma unroll
@@ -73,20 +80,26 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int key = 32 * k2 + 8 * (c >> 2) + 4 * t + (c & 3);  // row permutation (see header)
-      bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(ks + kswz(key, g));
-      bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(ks + kswz(key, 4 + g));
+      bf16x8 kf[S][2];
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc) {
+        kf[pc][0] = *reinterpret_cast<const bf16x8*>(ks + pc * 128 * 128 + kswz(key, g));
+        kf[pc][1] = *reinterpret_cast<const bf16x8*>(ks + pc * 128 * 128 + kswz(key, 4 + g));
+      }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-        a = mfma16(kf0, qf[nt][0], a);
-        a = mfma16(kf1, qf[nt][1], a);
+#pragma unroll
+        for (int pr = 0; pr < T::NP; ++pr) {
+          a = mfma16(kf[T::A[pr]][0], qf[T::B[pr]][nt][0], a);
+          a = mfma16(kf[T::A[pr]][1], qf[T::B[pr]][nt][1], a);
+        }
         s[k2][t][nt] = a;
       }
     }
 
-  // bias + mask, softmax over keys for this lane's query column(s)
-  float inv_l[2];
-  bf16x8 pf[NKS][2];
+  // bias + mask, row maximum over keys for this lane's query column(s)
+  float mxq[2], l[2] = {0.f, 0.f};
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int query = q0 + 16 * nt + c;
@@ -105,69 +118,111 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
         }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float l = 0.f;
-#pragma unroll
-    for (int k2 = 0; k2 < NKS; ++k2) {
-      bf16x8 f;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float e = __expf(s[k2][t][nt][j] - mx);
-          l += e;
-          f[4 * t + j] = (bf16)e;
-        }
-      pf[k2][nt] = f;
-    }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    inv_l[nt] = 1.f / l;
+    mxq[nt] = mx;
   }
 
-  // O^T = V^T P^T
+  // O^T = V^T P^T, P = exp(S^T - max) formed 32 keys at a time (as bf16 pieces) right before its MFMAs
   f32x4 o[4][2];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) o[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int k2 = 0; k2 < NKS; ++k2)
+  for (int k2 = 0; k2 < NKS; ++k2) {
+    bf16x8 pf[S][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float e = __expf(s[k2][t][nt][j] - mxq[nt]);
+          l[nt] += e;
+#pragma unroll
+          for (int pc = 0; pc < S; ++pc) {
+            const bf16 b = (bf16)e;
+            pf[pc][nt][4 * t + j] = b;
+            e -= (float)b;
+          }
+        }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int d = 16 * mt + c;
-      bf16x8 vf = *reinterpret_cast<const bf16x8*>(vts + vtswz(d, 32 * k2 + 8 * g));
+      bf16x8 vf[S];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) o[mt][nt] = mfma16(vf, pf[k2][nt], o[mt][nt]);
+      for (int pc = 0; pc < S; ++pc) vf[pc] = *reinterpret_cast<const bf16x8*>(vts + pc * 64 * 256 + vtswz(d, 32 * k2 + 8 * g));
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int pr = 0; pr < T::NP; ++pr) o[mt][nt] = mfma16(vf[T::A[pr]], pf[T::B[pr]][nt], o[mt][nt]);
     }
+  }
 
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
+    float lt = l[nt];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const float inv_l = 1.f / lt;
     const int query = q0 + 16 * nt + c;
     bf16* orow = out + ((size_t)p * L + query) * inner + h * 64;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      bf16x4 r;
+      f32x4 v = o[mt][nt] * inv_l;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] = (bf16)(o[mt][nt][j] * inv_l[nt]);
-      *reinterpret_cast<bf16x4*>(orow + 16 * mt + 4 * g) = r;
+      for (int pc = 0; pc < S; ++pc) {
+        bf16x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          r[j] = (bf16)v[j];
+          v[j] -= (float)r[j];
+        }
+        *reinterpret_cast<bf16x4*>(orow + pc * out_pstride + 16 * mt + 4 * g) = r;
+      }
     }
   }
+}
+
+template <int S>
+int launch_enc(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H, long qkv_pstride,
+               long out_pstride, hipStream_t st) {
+  const dim3 grid(H, P), block(256);
+  constexpr int smem = S * 2 * 128 * 128 + (256 + 128) * 4;
+  static bool attr_set = false;
+  if (!attr_set && smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<1, S>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<2, S>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<3, S>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<4, S>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  switch (L / 32) {
+    case 1: hipLaunchKernelGGL((enc_attn_kernel<1, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride, out_pstride); break;
+    case 2: hipLaunchKernelGGL((enc_attn_kernel<2, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride, out_pstride); break;
+    case 3: hipLaunchKernelGGL((enc_attn_kernel<3, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride, out_pstride); break;
+    default: hipLaunchKernelGGL((enc_attn_kernel<4, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride, out_pstride); break;
+  }
+  GRAM_CHECK_LAUNCH();
+  return 0;
 }
 
 }  // namespace
 
 extern "C" int gram_enc_self_attn(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H,
                                   void* stream) {
-  if (P < 1 || H < 1 || L < 32 || L > GRAM_MAX_PASSAGE_LEN || (L & 31)) return GRAM_E_ARG;
-  dim3 grid(H, P), block(256);
+  return gram_enc_self_attn_split(qkv, bias, mask, out, P, L, H, 1, 0, 0, stream);
+}
+
+extern "C" int gram_enc_self_attn_split(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H,
+                                        int pieces, int64_t qkv_pstride, int64_t out_pstride, void* stream) {
+  if (P < 1 || H < 1 || L < 32 || L > GRAM_MAX_PASSAGE_LEN || (L & 31) || pieces < 1 || pieces > GRAM_MAX_PIECES) return GRAM_E_ARG;
+  if (pieces > 1 && (qkv_pstride < (int64_t)P * L * 3 * H * 64 || out_pstride < (int64_t)P * L * H * 64)) return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  gram_prof::Scope prof(GRAM_K_ENC_ATTN, st, 4.0 * P * H * L * L * 64);
-  switch (L / 32) {
-    case 1: hipLaunchKernelGGL(enc_attn_kernel<1>, grid, block, 0, st, (const bf16*)qkv, bias, mask, (bf16*)out, H); break;
-    case 2: hipLaunchKernelGGL(enc_attn_kernel<2>, grid, block, 0, st, (const bf16*)qkv, bias, mask, (bf16*)out, H); break;
-    case 3: hipLaunchKernelGGL(enc_attn_kernel<3>, grid, block, 0, st, (const bf16*)qkv, bias, mask, (bf16*)out, H); break;
-    default: hipLaunchKernelGGL(enc_attn_kernel<4>, grid, block, 0, st, (const bf16*)qkv, bias, mask, (bf16*)out, H); break;
+  gram_prof::Scope prof(GRAM_K_ENC_ATTN, st, 4.0 * P * H * L * L * 64 * GRAM_SPLIT_NPROD[pieces]);
+  switch (pieces) {
+    case 1: return launch_enc<1>(qkv, bias, mask, out, P, L, H, qkv_pstride, out_pstride, st);
+    case 2: return launch_enc<2>(qkv, bias, mask, out, P, L, H, qkv_pstride, out_pstride, st);
+    default: return launch_enc<3>(qkv, bias, mask, out, P, L, H, qkv_pstride, out_pstride, st);
   }
-  GRAM_CHECK_LAUNCH();
-  return 0;
 }

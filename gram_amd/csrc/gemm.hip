@@ -35,9 +35,9 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
-enum { V_DMA_M64 = 31, V_REG2 = 0, V_DMA = 1, V_DMA2 = 2, V_DMA_M256 = 3, V_DMA2_M256 = 4, V_DMA2_256SQ = 5, V_DMA_256SQ = 6, V_RING = 7, V_IL = 8, V_PP = 22 };
+enum { V_DMA_M64 = 31, V_REG2 = 0, V_DMA = 1, V_DMA_M256 = 3, V_PP = 22 };  // (ids kept from the variant table of round 1)
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
-int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain), see gemm_il_kernel
+int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain)
 
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -63,7 +63,19 @@ struct EpiArgs {
   // ping-pong KV-bank epilogue: divisions by runtime values as multiply-high (scalar ALU; a division sequence costs
   // a dozen VGPRs the kernel does not have).  mg_x = floor(2^32 / x) + 1; exact for the dividends documented at use.
   uint32_t mg_pL32, mg_S32, mg_pN, mg_it;  // x = pL/32, S/32, pN, inner/256
+  // split-bf16 outputs (gram_split_t): every bf16 result (C of the bf16 epilogues, xb_out, the bank) is written as `split` pieces
+  // p0 = bf16(v), p1 = bf16(v - p0), ...; piece p lives `*_pstride` elements after piece p - 1
+  int split;
+  long c_pstride, xb_pstride, bank_pstride;
 };
+// Split-bf16 reduction (gram_split_t): the k-loop runs over np chunks of nktc k-tiles; chunk c multiplies piece (amap >> 4c) & 15 of A
+// (the [M][lda] matrix a_pstride elements after piece 0's) with columns c * kc + k of the product-expanded W.  np = 1: the plain GEMM.
+struct KSplit {
+  int np, nktc, kc;
+  uint32_t amap;
+  long a_pstride;  // elements between the bf16 pieces of A
+};
+__device__ __forceinline__ long ks_acol(const KSplit& ks, int c) { return (long)((ks.amap >> (4 * c)) & 15u) * ks.a_pstride; }
 inline uint32_t magic_u32(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }
 __device__ __forceinline__ uint32_t udiv_magic(uint32_t x, uint32_t d, uint32_t mg) { return d <= 1 ? x : __umulhi(x, mg); }
 
@@ -148,6 +160,14 @@ __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
   for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
   return __builtin_bit_cast(uint2, o);
 }
+__device__ __forceinline__ f32x4 unpack_bf16x4(uint2 u) {
+  f32x4 r;
+  r[0] = __uint_as_float(u.x << 16);
+  r[1] = __uint_as_float(u.x & 0xffff0000u);
+  r[2] = __uint_as_float(u.y << 16);
+  r[3] = __uint_as_float(u.y & 0xffff0000u);
+  return r;
+}
 
 template <int EPI, int TNW>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, int wm, int wn, int r16, int g, int M,
@@ -168,16 +188,22 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
             v1[e] = fmaxf(v1[e], 0.f);
           }
         }
-        const uint2 lo = pack_bf16x4(v0), hi = pack_bf16x4(v1);
         const bool odd = g & 1;
-        const uint2 send = odd ? lo : hi;
-        uint2 recv;
-        recv.x = __shfl_xor(send.x, 16, 64);
-        recv.y = __shfl_xor(send.y, 16, 64);
-        // even g: tile i, columns 8*(g/2)..+7 = [own lo | partner's lo]; odd g: tile i+1 = [partner's hi | own hi]
-        const uint4 out = odd ? make_uint4(recv.x, recv.y, hi.x, hi.y) : make_uint4(lo.x, lo.y, recv.x, recv.y);
         const int n = n0 + wn * 16 * TNW + (i + (odd ? 1 : 0)) * 16 + 8 * (g >> 1);
-        if (row_ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + n) = out;
+        for (int pc = 0; pc < ep.split; ++pc) {  // (one pass unless the output is split into bf16 pieces)
+          const uint2 lo = pack_bf16x4(v0), hi = pack_bf16x4(v1);
+          const uint2 send = odd ? lo : hi;
+          uint2 recv;
+          recv.x = __shfl_xor(send.x, 16, 64);
+          recv.y = __shfl_xor(send.y, 16, 64);
+          // even g: tile i, columns 8*(g/2)..+7 = [own lo | partner's lo]; odd g: tile i+1 = [partner's hi | own hi]
+          const uint4 out = odd ? make_uint4(recv.x, recv.y, hi.x, hi.y) : make_uint4(lo.x, lo.y, recv.x, recv.y);
+          if (row_ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(ep.C) + pc * ep.c_pstride + (size_t)m * ep.ldc + n) = out;
+          if (pc + 1 < ep.split) {
+            v0 -= unpack_bf16x4(lo);
+            v1 -= unpack_bf16x4(hi);
+          }
+        }
       }
     } else if constexpr (EPI == GRAM_EPI_F32_LSE) {
       // logits + softmax partials of this wave's 64-column block (TNW == 4): a lane holds 16 of the
@@ -226,7 +252,12 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
           const f32x4 nv = *p + v;
           *p = nv;
           if (ep.xb_out) {
-            *reinterpret_cast<uint2*>(ep.xb_out + (size_t)m * ep.ldc + n) = pack_bf16x4(nv);
+            f32x4 rem = nv;
+            for (int pc = 0; pc < ep.split; ++pc) {
+              const uint2 pk = pack_bf16x4(rem);
+              *reinterpret_cast<uint2*>(ep.xb_out + pc * ep.xb_pstride + (size_t)m * ep.ldc + n) = pk;
+              rem -= unpack_bf16x4(pk);
+            }
             ssq[i / 4] += (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
           }
         } else if constexpr (EPI == GRAM_EPI_F32) {
@@ -246,12 +277,16 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
           const int rem = n - lw * ep.inner;
           const int h = rem >> 6, d = rem & 63;
           const size_t head = ((size_t)layer * ep.B + b) * ep.H + h;
-          if (which == 0) {
+          for (int pc = 0; pc < ep.split; ++pc) {
             const uint2 o = pack_bf16x4(v);
-            *reinterpret_cast<uint2*>(ep.bank_k + (head * ep.S + s) * 64 + d) = o;
-          } else {
+            if (which == 0) {
+              *reinterpret_cast<uint2*>(ep.bank_k + pc * ep.bank_pstride + (head * ep.S + s) * 64 + d) = o;
+            } else {
+              const bf16x4 ob = __builtin_bit_cast(bf16x4, o);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ep.bank_vt[(head * 64 + d + e) * ep.S + s] = (bf16)v[e];
+              for (int e = 0; e < 4; ++e) ep.bank_vt[pc * ep.bank_pstride + (head * 64 + d + e) * ep.S + s] = ob[e];
+            }
+            v -= unpack_bf16x4(o);
           }
         }
         }
@@ -274,7 +309,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
 // ---------------------------------------------------------------------------------------------
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_reg2_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M,
-                                                           int N, int K, int lda, EpiArgs ep) {
+                                                           int N, int K, int lda, EpiArgs ep, KSplit ks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -298,9 +333,11 @@ __global__ __launch_bounds__(256, 2) void gemm_reg2_kernel(const bf16* __restric
   }
   bf16x8 ra[4], rw[4];
   auto load_tile = [&](int kt) {
+    const int c = kt / ks.nktc;  // (np == 1: c = 0 and the A column is kt * BK)
+    const long acol = ks_acol(ks, c) + (kt - c * ks.nktc) * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = a_ok[i] ? ld_global_b128(a_src[i] + kt * BK) : zero_bf16x8();
+      ra[i] = a_ok[i] ? ld_global_b128(a_src[i] + acol) : zero_bf16x8();
       rw[i] = ld_global_b128(w_src[i] + kt * BK);
     }
   };
@@ -372,7 +409,12 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
         *pc = val;
         if constexpr (EPI == GRAM_EPI_F32_ADD) {
           if (ep.xb_out) {
-            *reinterpret_cast<uint2*>(ep.xb_out + (size_t)m * ep.ldc + n0 + wn * 64 + c * 4) = pack_bf16x4(val);
+            f32x4 rem = val;
+            for (int pc = 0; pc < ep.split; ++pc) {
+              const uint2 pk = pack_bf16x4(rem);
+              *reinterpret_cast<uint2*>(ep.xb_out + pc * ep.xb_pstride + (size_t)m * ep.ldc + n0 + wn * 64 + c * 4) = pk;
+              rem -= unpack_bf16x4(pk);
+            }
             ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
           }
         }
@@ -406,7 +448,7 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
 // sequence per accumulator, same epilogue code).
 template <int EPI, int MT>  // MT = m-tiles of 16 rows per workgroup that exist (M <= 16 * MT, or MT = 4 and a grid row per 64 rows)
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                          int K, int lda, EpiArgs ep) {
+                                                          int K, int lda, EpiArgs ep, KSplit ks) {
   __shared__ f32x4 xch[4][MT][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
@@ -425,22 +467,26 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
   // U k-blocks (32 wide) of loads in flight, then their MFMAs (a second register set with the next loads already under
   // way was measured slower: 13.0 vs 11.4 ms of GEMM time per generate at B = 1)
   constexpr int U = 8;
-  const int nkb = K >> 5;
-  for (int kb = 0; kb < nkb; kb += U) {
-    bf16x8 fw[U], fa[U][MT];
+  const int nkb = ks.kc >> 5;  // k-blocks per chunk (one chunk = all of K unless the operands are split into bf16 pieces)
+  for (int c = 0; c < ks.np; ++c) {
+    const long acol = ks_acol(ks, c);
+    const int wcol = c * ks.kc;
+    for (int kb = 0; kb < nkb; kb += U) {
+      bf16x8 fw[U], fa[U][MT];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = min(kb + u, nkb - 1) << 5;  // (past the end: a valid re-read, not used)
-      fw[u] = ld_global_b128(wp + k);
+      for (int u = 0; u < U; ++u) {
+        const int k = min(kb + u, nkb - 1) << 5;  // (past the end: a valid re-read, not used)
+        fw[u] = ld_global_b128(wp + wcol + k);
 #pragma unroll
-      for (int j = 0; j < MT; ++j) fa[u][j] = a_ok[j] ? ld_global_b128(ap[j] + k) : zero_bf16x8();
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (kb + u < nkb) {
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc1[j] = mfma16(fw[u], fa[u][j], acc1[j]);
+        for (int j = 0; j < MT; ++j) fa[u][j] = a_ok[j] ? ld_global_b128(ap[j] + acol + k) : zero_bf16x8();
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (kb + u < nkb) {
+#pragma unroll
+          for (int j = 0; j < MT; ++j) acc1[j] = mfma16(fw[u], fa[u][j], acc1[j]);
+        }
+    }
   }
 #pragma unroll
   for (int j = 0; j < MT; ++j) xch[wave][j][lane] = acc1[j];
@@ -464,12 +510,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
 }
 
 template <int EPI>
-int launch_skinny(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+int launch_skinny(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
   if (M < 1 || N % 64 || K % 32 || (M + 63) / 64 > 65535) return GRAM_E_ARG;
   const dim3 grid(N / 64, (M + 63) / 64), block(256);
-  if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
-  else if (M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
-  else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
+  if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep, ks);
+  else if (M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep, ks);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep, ks);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -477,7 +523,7 @@ int launch_skinny(const void* A, const void* W, int M, int N, int K, int lda, Ep
 // ---------------------------------------------------------------------------------------------
 template <int EPI, int WM, int NST, int TNW>
 __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void gemm_dma_kernel(
-    const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, int lda, EpiArgs ep) {
+    const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks) {
   // WM x 2 waves, block tile (64*WM) x 128.  NST = 1: single LDS stage, latency hidden by the other
   // resident workgroups.  NST = 2: the DMA of k-tile kt+1 is issued before the MFMAs of k-tile kt and
   // drained by the (single) barrier after them.
@@ -515,9 +561,11 @@ __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void
   auto dma = [&](int kt, int stage) {
     char* sa = smem + stage * STAGE;
     char* sw = sa + A_BYTES;
+    const int c = kt / ks.nktc;  // (np == 1: c = 0 and the A column is kt * BK)
+    const long acol = ks_acol(ks, c) + (kt - c * ks.nktc) * BK;
 #pragma unroll
     for (int i = 0; i < AG; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * BK),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + acol),
                                        (__attribute__((address_space(3))) void*)(sa + (wave * AG + i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < WG; ++i)
@@ -558,364 +606,6 @@ __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void
     }
   }
   epilogue<EPI, TNW>(acc, m0, n0, wm, wn, r16, g, M, ep, rs4);
-}
-
-// ---------------------------------------------------------------------------------------------
-// V_RING: 256x256 tile, 8 waves (4 x 2, wave tile 64 x 128), k-stages of 32 in a 4-slot LDS ring
-// (4 x 32 KiB = 128 KiB): three stages (96 KiB) are always in flight while the fourth is consumed.
-// Counter profiles of the simpler variants showed the MFMA pipe ~37 % busy, zero bank conflicts,
-// and an L2->LDS fill rate pinned at bytes-in-flight / DMA latency; this variant raises the bytes
-// in flight per CU instead of the occupancy.  DMA completion is tracked with COUNTED s_waitcnt
-// vmcnt(N) (each wave issues exactly 4 DMA instructions per stage) and a raw s_barrier, so the
-// prefetch stays in flight across the barrier (__syncthreads() would drain it).
-// Stage tiles are [256 rows][32 k] bf16 = 64-B rows; 16-B chunk swizzle chunk ^= F[(row>>2)&3],
-// F = {0,2,3,1}, conflict-free for the ds_read_b128 lane groups (derivation in DESIGN.md).
-__device__ __forceinline__ int fsw(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
-__device__ __forceinline__ int swz32(int row, int chunk) { return row * 64 + ((chunk ^ fsw(row)) << 4); }
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                           int K, int lda, EpiArgs ep) {
-  constexpr int TB = 256, SK = 32, OPB = TB * SK * 2 /*16 KiB*/, STAGE = 2 * OPB, NSLOT = 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  int mt, nt;
-  tile_of_block(N / TB, mt, nt);
-  const int m0 = mt * TB, n0 = nt * TB;
-  const int r16 = lane & 15, g = lane >> 4;
-
-  // DMA map: one wave instruction = 16 rows x 64 B (1 KiB, lane-linear): lane l -> row 16*grp + (l>>2),
-  // slot l&3, fetching chunk slot ^ F.  Each operand stage is 16 groups; wave w owns groups 2w, 2w+1.
-  const bf16* a_src[2];
-  const bf16* w_src[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wave * 2 + i) * 16 + (lane >> 2);
-    const int chunk = (lane & 3) ^ fsw(row);
-    a_src[i] = A + (size_t)min(m0 + row, M - 1) * lda + chunk * 8;
-    w_src[i] = W + (size_t)(n0 + row) * K + chunk * 8;
-  }
-  auto dma = [&](int kt) {
-    char* sa = smem + (kt & (NSLOT - 1)) * STAGE;
-    char* sw = sa + OPB;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * SK),
-                                       (__attribute__((address_space(3))) void*)(sa + (wave * 2 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + kt * SK),
-                                       (__attribute__((address_space(3))) void*)(sw + (wave * 2 + i) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = K / SK;
-  float rs4[4];
-  load_row_scales(ep, m0 + wm * 64, r16, M, rs4);
-  dma(0);
-  if (nk > 1) dma(1);
-  if (nk > 2) dma(2);
-  for (int kt = 0; kt < nk; ++kt) {
-    // retire this wave's share of stage kt, leaving the younger stages in flight
-    const int ahead = min(2, nk - 1 - kt);
-    if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // stage kt complete for every wave; slot (kt-1)&3 no longer read
-    if (kt + 3 < nk) dma(kt + 3);
-    const char* sa = smem + (kt & (NSLOT - 1)) * STAGE;
-    const char* sw = sa + OPB;
-    bf16x8 fw[8], fa[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(sw + swz32(wn * 128 + i * 16 + r16, g));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz32(wm * 64 + i * 16 + r16, g));
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
-  }
-  epilogue<EPI, 8>(acc, m0, n0, wm, wn, r16, g, M, ep, rs4);
-}
-
-template <int EPI>
-int launch_ring(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
-  constexpr int smem = 4 * 2 * 256 * 32 * 2;  // 128 KiB
-  if (N % 256 || K % 32) return GRAM_E_ARG;
-  const int nblocks = (N / 256) * ((M + 255) / 256);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_ring_kernel<EPI>, dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
-  GRAM_CHECK_LAUNCH();
-  return 0;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Row-contiguous epilogue for the 256x256 kernel (wave tile 64 rows x 128 columns).  The direct
-// epilogue touches 16 half-lines per store instruction (16 rows x 64 B) and is store-issue-bound
-// (ablation in tests/bench_gemm.py: ~60 % of the store cost remains even when the stores hit a
-// cache-resident region).  Here each wave transposes its accumulators through a PRIVATE 8-KiB LDS
-// patch (the second DMA stage is idle during the epilogue) and then issues stores/RMWs that cover
-// whole rows: 4 rows x 256 B (bf16) or 2 rows x 512 B (fp32) per instruction, full 128-B lines only.
-// 16-byte chunks are XOR-swizzled by row so both the transposing writes and the row reads are
-// conflict-free.  Wave-private: no workgroup barrier, only the wave's own LDS ordering.
-template <int EPI>
-__device__ __forceinline__ void epilogue_rows(f32x4 (&acc)[8][4], char* patch /* this wave's 8 KiB */, int m0, int n0, int wm,
-                                              int wn, int lane, int M, const EpiArgs& ep, const float (&rs4)[4]) {
-  const int r16 = lane & 15, g = lane >> 4;
-  if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
-    // two passes of 32 rows x 128 cols bf16: patch[32][256 B], chunk c (16 B) stored at c ^ (row & 15)
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = pass * 2 + jj;
-        const int row = jj * 16 + r16;
-        const float rs = rs4[j];  // folded T5LayerNorm (1 if unused)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          f32x4 v = acc[i][j] * rs;
-          if constexpr (EPI == GRAM_EPI_BF16_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          // 8-byte piece: columns i*16 + 4g .. +3  -> chunk (i*2 + g/2), half (g&1)
-          const int chunk = (i * 2 + (g >> 1)) ^ (row & 15);
-          *reinterpret_cast<uint2*>(patch + row * 256 + chunk * 16 + (g & 1) * 8) = pack_bf16x4(v);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = it * 4 + (lane >> 4), c = lane & 15;
-        const uint4 val = *reinterpret_cast<const uint4*>(patch + row * 256 + ((c ^ (row & 15)) * 16));
-        const int m = m0 + wm * 64 + pass * 32 + row;
-        if (m < M) store16(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 8, val, ep.nt);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  } else {
-    // fp32: four passes of 16 rows x 128 cols: patch[16][512 B], chunk c (16 B, 32 per row) at c ^ (row & 15)*2
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // F32_ADD: all 8 residual loads of the pass go out FIRST (32 registers, freed accumulators later on) -- written
-      // inline below, hipcc emits load -> s_waitcnt vmcnt(0) -> store per row pair: 32 exposed HBM round trips per wave
-      f32x4 res[8];
-      if constexpr (EPI == GRAM_EPI_F32_ADD) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          const int m = min(m0 + wm * 64 + j * 16 + it * 2 + (lane >> 5), M - 1);  // (rows past M: loaded, never stored)
-          res[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + (lane & 31) * 4);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int chunk = (i * 4 + g) ^ ((r16 & 15) << 1);
-        *reinterpret_cast<f32x4*>(patch + r16 * 512 + chunk * 16) = acc[i][j];
-      }
-      __builtin_amdgcn_wave_barrier();
-      float ssq8[8];  // per-lane partials of the pass; reduced across lanes AFTER the loop (8 independent butterflies
-                      // pipeline through the LDS crossbar; one per iteration was a dependent round trip each)
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = it * 2 + (lane >> 5), c = lane & 31;
-        f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 512 + ((c ^ ((row & 15) << 1)) * 16));
-        const int m = m0 + wm * 64 + j * 16 + row;
-        float ssq = 0.f;
-        if (m < M) {
-          f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4);
-          if constexpr (EPI == GRAM_EPI_F32_ADD) val += res[it];
-          store16(pc, val, ep.nt);
-          if constexpr (EPI == GRAM_EPI_F32_ADD) {
-            if (ep.xb_out) {
-              store8(ep.xb_out + (size_t)m * ep.ldc + n0 + wn * 128 + c * 4, pack_bf16x4(val), ep.nt);
-              ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
-            }
-          }
-        }
-        ssq8[it] = ssq;
-      }
-      if constexpr (EPI == GRAM_EPI_F32_ADD) {
-        if (ep.ss_out) {  // 16 lanes cover one 64-column block of one row
-#pragma unroll
-          for (int sh = 1; sh < 16; sh <<= 1)
-#pragma unroll
-            for (int it = 0; it < 8; ++it) ssq8[it] += __shfl_xor(ssq8[it], sh, 64);
-#pragma unroll
-          for (int it = 0; it < 8; ++it) {
-            const int c = lane & 31, m = m0 + wm * 64 + j * 16 + it * 2 + (lane >> 5);
-            if ((c & 15) == 0 && m < M) ep.ss_out[(size_t)m * ep.ss_out_nblk + ((n0 + wn * 128) >> 6) + (c >> 4)] = ssq8[it];
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// V_IL: the 256x256 double-buffered DMA variant with the next k-tile's 8 DMA instructions
-// INTERLEAVED between MFMA groups (one DMA after every 8 MFMAs) instead of issued back-to-back
-// after the barrier: an LDS-DMA instruction costs ~100+ issue cycles inside a busy phase, and in the
-// plain variant all 8 waves pay 8 of them at the same moment while the MFMA pipe idles.
-template <int EPI, int ABL = 0>  // ABL (ablation, microbench only): 1 = DMA only, 2 = MFMA only, 3 = no stores
-__global__ __launch_bounds__(512, 2) void gemm_il_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                         int K, int lda, EpiArgs ep, int ntiles, int stagger) {
-  // PERSISTENT: one workgroup per CU walks tiles t = round*G + slot.  With one 128-KiB workgroup per
-  // CU all CUs run in lockstep, so a per-tile launch leaves the output stream (up to 1.2 GB per GEMM)
-  // un-overlapped with MFMA work; here the stores of tile i drain while tile i+1 is fetched/computed,
-  // and the first DMA stage of tile i+1 is issued BEFORE the epilogue of tile i.
-  constexpr int TB = 256, OPB = TB * BK * 2 /*32 KiB*/, STAGE = 2 * OPB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r16 = lane & 15, g = lane >> 4;
-  const int ntn = N / TB;
-  // XCD-aware slot: workgroups b, b+8, ... share an XCD; give each XCD a contiguous run of every round
-  const int G = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, local = bid >> 3, q = G >> 3, rr = G & 7;
-  const int slot = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
-
-  const bf16* src[8];  // pieces 0-3: A groups 4w..4w+3, pieces 4-7: W groups 4w..4w+3
-  auto set_tile = [&](int tile, int& m0, int& n0) {
-    const int mt = tile / ntn, nt = tile - mt * ntn;
-    m0 = mt * TB;
-    n0 = nt * TB;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave * 4 + i) * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      src[i] = A + (size_t)min(m0 + row, M - 1) * lda + chunk * 8;
-      src[4 + i] = W + (size_t)(n0 + row) * K + chunk * 8;
-    }
-  };
-  auto dma_piece = [&](int kt, int stage, int p) {
-    char* dst = smem + stage * STAGE + (p >= 4 ? OPB : 0) + (wave * 4 + (p & 3)) * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[p] + kt * BK),
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
-
-  f32x4 acc[8][4];
-  bf16x8 fw0[8], fa0[4];
-  auto ldfrag = [&](bf16x8 (&fw)[8], bf16x8 (&fa)[4], const char* sa, const char* sw, int ks) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 128 + i * 16 + r16, ks * 4 + g));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + r16, ks * 4 + g));
-  };
-  auto mma = [&](bf16x8 (&fw)[8], bf16x8 (&fa)[4], int kt, int st, int ks, bool more) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if constexpr (ABL != 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw[i], fa[j], acc[i][j]);
-      }
-      if ((i & 1) == 1) {
-        if (more && ABL != 2) dma_piece(kt + 1, st ^ 1, ks * 4 + (i >> 1));
-        __builtin_amdgcn_sched_barrier(0);  // keep the DMA between these MFMA groups
-      }
-    }
-  };
-
-  const int nkt = K / BK;  // nkt is even or odd; the stage parity restarts at 0 for every tile
-  // De-synchronise the CUs: identical tiles keep all 256 workgroups in lockstep, so their epilogues
-  // would hit HBM as one 32-MB burst that every workgroup then waits out at its next barrier.  A start
-  // stagger of (slot % 8) * ~1/8 tile period spreads the store traffic over the whole period.
-  if (stagger > 0) {
-    const int units = ((slot & 7) * stagger * nkt) >> 3;
-    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);  // 8 * 64 = 512 cycles
-  }
-  int tile = slot;
-  int m0 = 0, n0 = 0;
-  if (tile < ntiles) {
-    set_tile(tile, m0, n0);
-#pragma unroll
-    for (int p = 0; p < 8; ++p) dma_piece(0, 0, p);
-  }
-  while (tile < ntiles) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float rs4[4];
-    load_row_scales(ep, m0 + wm * 64, r16, M, rs4);  // consumed by the epilogue; latency hidden by the k-loop
-    __syncthreads();  // stage 0 of this tile landed (and the previous tile's stores are issued/drained)
-    for (int kt = 0; kt < nkt; ++kt) {
-      const int st = kt & 1;
-      const bool more = kt + 1 < nkt;
-      const char* sa = smem + st * STAGE;
-      const char* sw = sa + OPB;
-      ldfrag(fw0, fa0, sa, sw, 0);
-      mma(fw0, fa0, kt, st, 0, more);
-      ldfrag(fw0, fa0, sa, sw, 1);
-      mma(fw0, fa0, kt, st, 1, more);
-      __syncthreads();  // drains DMA(kt+1), fences the reads of stage st
-    }
-    // next tile: start its first stage now (both LDS stages are free), then store this tile
-    const int cur_m0 = m0, cur_n0 = n0;
-    tile += G;
-    if (tile < ntiles) {
-      set_tile(tile, m0, n0);
-#pragma unroll
-      for (int p = 0; p < 8; ++p) dma_piece(0, 0, p);
-    }
-    if constexpr (ABL == 3) {  // ablation: no stores (keep acc live)
-      float keep = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-      if (keep == 123.456f) reinterpret_cast<float*>(ep.C)[0] = keep;
-    } else if constexpr (ABL == 4) {  // ablation: same stores, but always into this workgroup's first tile (cache-resident)
-      epilogue<EPI, 8>(acc, (slot / ntn) * TB, (slot % ntn) * TB, wm, wn, r16, g, M, ep, rs4);
-    } else if constexpr (EPI == GRAM_EPI_KV_BANK) {
-      epilogue<EPI, 8>(acc, cur_m0, cur_n0, wm, wn, r16, g, M, ep, rs4);
-    } else {
-      // stage 1 is idle here (the next tile's first DMA went to stage 0): 8 waves x 8 KiB patches
-      epilogue_rows<EPI>(acc, smem + STAGE + wave * 8192, cur_m0, cur_n0, wm, wn, lane, M, ep, rs4);
-    }
-  }
-}
-
-template <int EPI, int ABL = 0>
-int launch_il(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
-  constexpr int smem = 2 * 2 * 256 * 64 * 2;  // 128 KiB
-  if (N % 256) return GRAM_E_ARG;
-  const int ntiles = (N / 256) * ((M + 255) / 256);
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GRAM_E_ARG;
-    n_cu = prop.multiProcessorCount;
-  }
-  const int nblocks = ntiles < n_cu ? ntiles : n_cu;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_il_kernel<EPI, ABL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  static const int nt_env = getenv("GRAM_GEMM_NT") ? atoi(getenv("GRAM_GEMM_NT")) : 0;
-  ep.nt = nt_env;
-  hipLaunchKernelGGL((gemm_il_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep,
-                     ntiles, g_stagger);
-  GRAM_CHECK_LAUNCH();
-  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1770,18 +1460,16 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
   }
 }
 
-// Measured on MI355X (tests/bench_gemm.py, B = 512 shapes; TFLOP/s):
-//   M >= 32768 (encoder, bank):  V_IL (persistent 256x256, row-contiguous epilogue) 935-948 (521 for the
-//                                HBM-bound N=768,K=768 residual GEMM) > V_DMA_M256 780-815 > V_DMA
-//   lm_head (N = 32128, not a multiple of 256):  V_DMA_M256 783 > V_DMA 614
-//   M ~ 10240 (decoder):         V_DMA 475-832 > V_DMA_M256 418-801 > V_IL 299-696 (too few tiles per CU)
+// Measured on MI355X (tests/bench_gemm.py; TFLOP/s):
+//   M >= 32768 (encoder, bank):  ping-pong 256x256 persistent kernel 1 100-1 190 > 256x128 tiles 780-815 > 128x128
+//   lm_head with logits stored (N = 32128, not a multiple of 256):  256x128 783 > 128x128 614
+//   M ~ 10240 (decoder):         128x128 475-832 > 256x128 418-801 > persistent 299-696 (too few tiles per CU)
 int pick_variant(int M, int N, int K) {
   if (g_force_variant >= 0) return g_force_variant;
   const long tiles256 = (long)((M + 255) / 256) * (N / BN);
-  static const int big = getenv("GRAM_GEMM_BIG") ? atoi(getenv("GRAM_GEMM_BIG")) : V_IL;  // A/B hook
   // persistent 256x256: needs >= ~2 tiles per CU to amortise its fill/drain; with a long K (FFN-wo, K = 4*d) it
   // already wins at 480 tiles (M = 40960, N = 768: 230 us vs 277 us for the 128x128 variant)
-  if (N % 256 == 0 && M >= 32768 && (tiles256 >= 2048 || K >= 2048)) return big;
+  if (N % 256 == 0 && M >= 32768 && (tiles256 >= 2048 || K >= 2048)) return V_PP;
   if (tiles256 >= 2048) return V_DMA_M256;
   // few 128 x 128 tiles (a batch of 4 .. ~100 users in the decoder): 64-row tiles double the workgroups that pull the weights
   static const int m64_max = getenv("GRAM_GEMM_M64_MAXTILES") ? atoi(getenv("GRAM_GEMM_M64_MAXTILES")) : 256;  // A/B hook; measured +1-2 % at B = 8 .. 256
@@ -1790,7 +1478,7 @@ int pick_variant(int M, int N, int K) {
 }
 
 template <int EPI, int WM, int NST, int TNW = 4>
-int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
   constexpr int TBM = 64 * WM, TBN = 32 * TNW;
   constexpr int smem = NST * (TBM + TBN) * BK * 2;
   if (N % TBN) return GRAM_E_ARG;
@@ -1805,7 +1493,7 @@ int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiAr
   static const int rows_env = getenv("GRAM_GEMM_DMAROWS") ? atoi(getenv("GRAM_GEMM_DMAROWS")) : 1;  // A/B hook; measured +1.2 % end to end
   if (rows_env) ep.nt |= 4;
   hipLaunchKernelGGL((gemm_dma_kernel<EPI, WM, NST, TNW>), dim3(nblocks), dim3(WM * 128), smem, st, (const bf16*)A, (const bf16*)W,
-                     M, N, K, lda, ep);
+                     M, N, K, lda, ep, ks);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -1813,71 +1501,44 @@ int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiAr
 constexpr int V_SKINNY = 30;
 
 template <int EPI>
-int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
-  gram_prof::Scope prof(GRAM_K_GEMM, st, 2.0 * M * N * K);
+int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
+  gram_prof::Scope prof(GRAM_K_GEMM, st, 2.0 * M * N * K);  // K = the executed reduction length (np * kc for split operands)
   if constexpr (EPI != GRAM_EPI_KV_BANK) {
     static const int use_skinny = getenv("GRAM_GEMM_SKINNY") ? atoi(getenv("GRAM_GEMM_SKINNY")) : 1;  // A/B hook
     static const int skinny_max_m = getenv("GRAM_GEMM_SKINNY_MAXM") ? atoi(getenv("GRAM_GEMM_SKINNY_MAXM")) : 64;  // A/B hook
     if (g_force_variant == V_SKINNY || (g_force_variant < 0 && use_skinny && M <= skinny_max_m && N % 64 == 0 && K % 32 == 0))
-      return launch_skinny<EPI>(A, W, M, N, K, lda, ep, st);
+      return launch_skinny<EPI>(A, W, M, N, K, lda, ep, ks, st);
   }
+  // The ping-pong kernel declines shapes it does not cover (GRAM_E_ARG); those run on the 256x128 tiles.
+  // GRAM_GEMM_PP=0 (A/B hook) keeps it out altogether.
+  static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
+  const bool pp_ok = use_pp && ks.np == 1;
   if constexpr (EPI == GRAM_EPI_F32_LSE) {  // 64-column wave tiles only: the ping-pong kernel (partials only) or the 128-row kernels
-    static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
-    if ((g_force_variant == V_PP || (g_force_variant < 0 && use_pp == 1 && M >= 32768)) && !ep.C) {
+    if ((g_force_variant == V_PP || (g_force_variant < 0 && pp_ok && M >= 32768)) && !ep.C) {
       const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
       if (r != GRAM_E_ARG) return r;
     }
     const int pv = pick_variant(M, N, K);
-    return pv == V_DMA_M64 ? launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, st)
-           : pv == V_DMA   ? launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st)
-                           : launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, st);
+    return pv == V_DMA_M64 ? launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, ks, st)
+           : pv == V_DMA   ? launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, ks, st)
+                           : launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, ks, st);
   } else {
   if constexpr (EPI == GRAM_EPI_F32_ADD) {  // big-M residual GEMMs: the ping-pong kernel with its tile-end epilogue, whatever N and K
-    static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
-    if (g_force_variant < 0 && (use_pp == 1 || use_pp == 2) && M >= 32768) {
+    if (g_force_variant < 0 && pp_ok && M >= 32768) {
       const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
       if (r != GRAM_E_ARG) return r;
     }
   }
   switch (pick_variant(M, N, K)) {
-    case V_DMA: return launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, st);
-    case V_DMA_M64: return launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, st);
-    case V_DMA2: return launch_dma<EPI, 2, 2>(A, W, M, N, K, lda, ep, st);
-    case V_DMA_M256: return launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, st);
-    case V_DMA2_M256: return launch_dma<EPI, 4, 2>(A, W, M, N, K, lda, ep, st);
-    case V_DMA2_256SQ: return launch_dma<EPI, 4, 2, 8>(A, W, M, N, K, lda, ep, st);
-    case V_DMA_256SQ: return launch_dma<EPI, 4, 1, 8>(A, W, M, N, K, lda, ep, st);
-    case V_RING: return launch_ring<EPI>(A, W, M, N, K, lda, ep, st);
-    case V_IL: {
-      // the ping-pong kernel is faster for bf16 outputs (+15 %) and for long-K fp32 residual GEMMs (+12-15 %, tile-end epilogue); it
-      // declines shapes it does not cover (GRAM_E_ARG) and those run on the plain persistent kernel
-      static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
-      if (use_pp && g_force_variant < 0 &&
-          (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || (EPI == GRAM_EPI_KV_BANK && use_pp != 3) ||
-           (EPI == GRAM_EPI_F32_ADD && use_pp != 3 && use_pp != 4))) {
+    case V_DMA: return launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, ks, st);
+    case V_DMA_M64: return launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, ks, st);
+    case V_PP:
+      if (g_force_variant == V_PP || pp_ok) {
         const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
-        if (r != GRAM_E_ARG) return r;
+        if (r != GRAM_E_ARG || g_force_variant == V_PP) return r;
       }
-      return launch_il<EPI>(A, W, M, N, K, lda, ep, st);
-    }
-    case 9: case 10: case 11: case 12:  // ablations of the DMA-interleaved kernel (bf16 epilogue only; bench_gemm.py)
-      if constexpr (EPI == GRAM_EPI_BF16) {
-        const int v = pick_variant(M, N, K);
-        return v == 9 ? launch_il<EPI, 1>(A, W, M, N, K, lda, ep, st) : v == 10 ? launch_il<EPI, 2>(A, W, M, N, K, lda, ep, st)
-             : v == 11 ? launch_il<EPI, 3>(A, W, M, N, K, lda, ep, st) : launch_il<EPI, 4>(A, W, M, N, K, lda, ep, st);
-      } else {
-        return GRAM_E_ARG;
-      }
-    case V_PP: return launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
-    case 23: case 24: case 25: case 26: case 27:  // ablations of the ping-pong kernel (bf16 epilogue only)
-      if constexpr (EPI == GRAM_EPI_BF16) {
-        const int v = pick_variant(M, N, K);
-        return v == 23 ? launch_pp<EPI, 3>(A, W, M, N, K, lda, ep, st) : v == 24 ? launch_pp<EPI, 2>(A, W, M, N, K, lda, ep, st)
-             : v == 25 ? launch_pp<EPI, 5>(A, W, M, N, K, lda, ep, st) : v == 26 ? launch_pp<EPI, 6>(A, W, M, N, K, lda, ep, st)
-                                                                       : launch_pp<EPI, 7>(A, W, M, N, K, lda, ep, st);
-      } else {
-        return GRAM_E_ARG;
-      }
+      [[fallthrough]];
+    case V_DMA_M256: return launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, ks, st);
     default: break;
   }
   const int nblocks = (N / BN) * ((M + BM - 1) / BM);
@@ -1889,7 +1550,7 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
     attr_set = true;
   }
   hipLaunchKernelGGL(gemm_reg2_kernel<EPI>, dim3(nblocks), dim3(256), 4 * TILE_BYTES, st, (const bf16*)A, (const bf16*)W, M, N,
-                     K, lda, ep);
+                     K, lda, ep, ks);
   GRAM_CHECK_LAUNCH();
   return 0;
   }
@@ -1906,27 +1567,73 @@ extern "C" int gram_debug_set_gemm_variant(int v) {
   return 0;
 }
 
-extern "C" int gram_gemm_bf16_lse(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int K, int lda,
-                                  int ldc, void* stream) {
-  if (M < 1 || N % BN != 0 || K % BK != 0 || lda < K || (lda & 7) || !lse_part || (logits && (ldc & 3))) return GRAM_E_ARG;
+namespace {
+// host side of gram_split_t: the chunk -> A piece map of the kernels (products smallest first, see gram_hip.h)
+int make_ksplit(const gram_split_t* sp, int kc, KSplit& ks, EpiArgs& ep) {
+  const int pieces = sp ? sp->pieces : 1;
+  if (pieces < 1 || pieces > GRAM_MAX_PIECES || kc % BK) return GRAM_E_ARG;
+  ks.np = GRAM_SPLIT_NPROD[pieces];
+  ks.kc = kc;
+  ks.nktc = kc / BK;
+  ks.amap = 0;
+  for (int c = 0; c < ks.np; ++c) ks.amap |= (uint32_t)GRAM_SPLIT_A_PIECE[pieces][c] << (4 * c);
+  ks.a_pstride = sp ? sp->a_pstride : 0;
+  ep.split = pieces;
+  ep.c_pstride = sp ? sp->c_pstride : 0;
+  ep.xb_pstride = sp ? sp->xb_pstride : 0;
+  ep.bank_pstride = sp ? sp->bank_pstride : 0;
+  if (pieces > 1 && ks.a_pstride < 1) return GRAM_E_ARG;
+  return 0;
+}
+}  // namespace
+
+extern "C" int gram_gemm_bf16_lse_split(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int kc, int lda,
+                                        int ldc, const gram_split_t* split, void* stream) {
+  if (M < 1 || N % BN != 0 || kc % BK != 0 || lda < kc || (lda & 7) || !lse_part || (logits && (ldc & 3))) return GRAM_E_ARG;
   EpiArgs ep{};
+  KSplit ks{};
+  const int r = make_ksplit(split, kc, ks, ep);
+  if (r) return r;
   ep.C = logits;
   ep.ldc = ldc;
   ep.lse_part = lse_part;
   ep.lse_nblk = N / 64;
-  return launch<GRAM_EPI_F32_LSE>(A, W, M, N, K, lda, ep, (hipStream_t)stream);
+  return launch<GRAM_EPI_F32_LSE>(A, W, M, N, ks.np * kc, lda, ep, ks, (hipStream_t)stream);
+}
+
+extern "C" int gram_gemm_bf16_lse(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int K, int lda,
+                                  int ldc, void* stream) {
+  return gram_gemm_bf16_lse_split(A, W, logits, lse_part, M, N, K, lda, ldc, nullptr, stream);
 }
 
 extern "C" int gram_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, int epilogue,
                               const gram_kv_bank_t* bank, void* stream) {
-  return gram_gemm_bf16_ex(A, W, C, M, N, K, lda, ldc, epilogue, bank, nullptr, stream);
+  return gram_gemm_bf16_split(A, W, C, M, N, K, lda, ldc, epilogue, bank, nullptr, nullptr, stream);
 }
 
 extern "C" int gram_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, int epilogue,
                                  const gram_kv_bank_t* bank, const gram_norm_fusion_t* nf, void* stream) {
-  if (M < 1 || N % BN != 0 || K % BK != 0 || lda < K || (lda & 7)) return GRAM_E_ARG;
+  return gram_gemm_bf16_split(A, W, C, M, N, K, lda, ldc, epilogue, bank, nf, nullptr, stream);
+}
+
+extern "C" int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M, int N, int kc, int lda, int ldc, int epilogue,
+                                    const gram_kv_bank_t* bank, const gram_norm_fusion_t* nf, const gram_split_t* split,
+                                    void* stream) {
+  if (M < 1 || N % BN != 0 || kc % BK != 0 || lda < kc || (lda & 7)) return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   EpiArgs ep{};
+  KSplit ks{};
+  {
+    const int r = make_ksplit(split, kc, ks, ep);
+    if (r) return r;
+  }
+  const int K = ks.np * kc;  // executed reduction length; W is [N][K]
+  if (ep.split > 1) {
+    const bool bf16_out = epilogue == GRAM_EPI_BF16 || epilogue == GRAM_EPI_BF16_RELU;
+    if ((bf16_out && ep.c_pstride < 1) || (epilogue == GRAM_EPI_KV_BANK && ep.bank_pstride < 1) ||
+        (epilogue == GRAM_EPI_F32_ADD && nf && nf->xb_out && ep.xb_pstride < 1))
+      return GRAM_E_ARG;
+  }
   ep.C = C;
   ep.ldc = ldc;
   if (nf) {
@@ -1948,16 +1655,16 @@ extern "C" int gram_gemm_bf16_ex(const void* A, const void* W, void* C, int M, i
   switch (epilogue) {
     case GRAM_EPI_BF16:
       if (!C || (ldc & 7)) return GRAM_E_ARG;  // 16-byte row-aligned bf16 stores
-      return launch<GRAM_EPI_BF16>(A, W, M, N, K, lda, ep, st);
+      return launch<GRAM_EPI_BF16>(A, W, M, N, K, lda, ep, ks, st);
     case GRAM_EPI_BF16_RELU:
       if (!C || (ldc & 7)) return GRAM_E_ARG;
-      return launch<GRAM_EPI_BF16_RELU>(A, W, M, N, K, lda, ep, st);
+      return launch<GRAM_EPI_BF16_RELU>(A, W, M, N, K, lda, ep, ks, st);
     case GRAM_EPI_F32_ADD:
       if (!C || (ldc & 3)) return GRAM_E_ARG;
-      return launch<GRAM_EPI_F32_ADD>(A, W, M, N, K, lda, ep, st);
+      return launch<GRAM_EPI_F32_ADD>(A, W, M, N, K, lda, ep, ks, st);
     case GRAM_EPI_F32:
       if (!C || (ldc & 3)) return GRAM_E_ARG;
-      return launch<GRAM_EPI_F32>(A, W, M, N, K, lda, ep, st);
+      return launch<GRAM_EPI_F32>(A, W, M, N, K, lda, ep, ks, st);
     case GRAM_EPI_KV_BANK: {
       if (!bank || !bank->k || !bank->vt) return GRAM_E_ARG;
       const int inner = bank->H * 64;
@@ -1976,7 +1683,7 @@ extern "C" int gram_gemm_bf16_ex(const void* A, const void* W, void* C, int M, i
       ep.pmap = bank->passage_map;
       ep.pL = bank->L;
       ep.pN = bank->N;
-      return launch<GRAM_EPI_KV_BANK>(A, W, M, N, K, lda, ep, st);
+      return launch<GRAM_EPI_KV_BANK>(A, W, M, N, K, lda, ep, ks, st);
     }
     default:
       return GRAM_E_ARG;

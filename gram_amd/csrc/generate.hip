@@ -66,6 +66,9 @@ struct Workspace {
   gram_live_rows_t live;
   int32_t* width;
   int64_t bytes;
+  // split-bf16 modes (gram_split_t): every bf16 buffer above is `pieces` copies, these many elements apart
+  int pieces;
+  int64_t ps_h, ps_qkv, ps_attn, ps_u, ps_bank, ps_hd, ps_qkvd, ps_attnd, ps_qx, ps_ud, ps_cache;
 };
 
 Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int Tmax) {
@@ -74,25 +77,38 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   const int64_t Me = (int64_t)B * N * L, S = (int64_t)N * L, R = (int64_t)B * K, nl = c.n_dec_layers;
   Carve cv(ws);
   Workspace w{};
+  const int64_t P = c.pieces > 1 ? c.pieces : 1;
+  w.pieces = (int)P;
+  w.ps_h = Me * d;
+  w.ps_qkv = Me * 3 * inner;
+  w.ps_attn = Me * inner;
+  w.ps_u = Me * F;
+  w.ps_bank = nl * B * c.n_heads * S * 64;
+  w.ps_hd = R * d;
+  w.ps_qkvd = R * 3 * inner;
+  w.ps_attnd = R * inner;
+  w.ps_qx = R * inner;
+  w.ps_ud = R * F;
+  w.ps_cache = nl * Tmax * R * inner;
   w.x = cv.take<float>(Me * d);
-  w.h = cv.take<bf16>(Me * d);
-  w.qkv = cv.take<bf16>(Me * 3 * inner);
-  w.attn = cv.take<bf16>(Me * inner);
-  w.u = cv.take<bf16>(Me * F);
+  w.h = cv.take<bf16>(P * w.ps_h);
+  w.qkv = cv.take<bf16>(P * w.ps_qkv);
+  w.attn = cv.take<bf16>(P * w.ps_attn);
+  w.u = cv.take<bf16>(P * w.ps_u);
   w.ss = cv.take<float>(Me * (d / 64));
   w.rs = cv.take<float>(Me);
-  w.bank_k = cv.take<bf16>(nl * B * c.n_heads * S * 64);
-  w.bank_vt = cv.take<bf16>(nl * B * c.n_heads * S * 64);
+  w.bank_k = cv.take<bf16>(P * w.ps_bank);
+  w.bank_vt = cv.take<bf16>(P * w.ps_bank);
   w.xd = cv.take<float>(R * d);
-  w.hd = cv.take<bf16>(R * d);
-  w.qkvd = cv.take<bf16>(R * 3 * inner);
-  w.attnd = cv.take<bf16>(R * inner);
-  w.qx = cv.take<bf16>(R * inner);
-  w.ud = cv.take<bf16>(R * F);
+  w.hd = cv.take<bf16>(P * w.ps_hd);
+  w.qkvd = cv.take<bf16>(P * w.ps_qkvd);
+  w.attnd = cv.take<bf16>(P * w.ps_attnd);
+  w.qx = cv.take<bf16>(P * w.ps_qx);
+  w.ud = cv.take<bf16>(P * w.ps_ud);
   w.ssd = cv.take<float>(R * (d / 64));
   w.rsd = cv.take<float>(R);
-  w.kcache = cv.take<bf16>(nl * Tmax * R * inner);
-  w.vcache = cv.take<bf16>(nl * Tmax * R * inner);
+  w.kcache = cv.take<bf16>(P * w.ps_cache);
+  w.vcache = cv.take<bf16>(P * w.ps_cache);
   w.logits = cv.take<float>(R * V);
   w.lse = cv.take<float>(R);
   w.lse_part = cv.take<float>(R * (V / 64) * 2);
@@ -140,6 +156,14 @@ constexpr int kPrecomputedRsRows = 32768;  // = the row count from which gemm.hi
     if (e__) return e__;  \
   } while (0)
 
+// One Linear of the path on (possibly split) operands: A (pieces a_ps apart) x W (product-expanded when pieces > 1);
+// c_ps = piece stride of whatever bf16 result the epilogue writes (C, xb_out or the bank).
+int linear(const Workspace& w, const void* A, int64_t a_ps, const void* W, void* C, int64_t c_ps, int M, int N, int kc, int lda, int ldc,
+           int epi, const gram_kv_bank_t* bank, const gram_norm_fusion_t* nf, void* st) {
+  const gram_split_t sp{w.pieces, a_ps, c_ps, c_ps, c_ps};
+  return gram_gemm_bf16_split(A, W, C, M, N, kc, lda, ldc, epi, bank, nf, &sp, st);
+}
+
 // The encoder layers on P passages (ids/mask [P][L]); leaves the residual stream in w.x rows [0, P*L).
 int encoder_layers(const gram_model* m, const Workspace& w, const int64_t* ids, const uint8_t* mask, int L, int P, void* st) {
   const gram_model_desc_t& c = m->d;
@@ -155,27 +179,27 @@ int encoder_layers(const gram_model* m, const Workspace& w, const int64_t* ids, 
     const bool pre_rs = Me >= kPrecomputedRsRows;
     const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rs, 0, d, c.eps}
                                               : gram_norm_fusion_t{nullptr, nullptr, w.ss, d / 64, d, c.eps};
-    TRY(gram_embed_ex(c.embed_f32, ids, 1, w.x, w.h, w.ss, d / 64, Me, d, st));
+    TRY(gram_embed_ex_split(c.embed_f32, ids, 1, w.x, w.h, w.ss, d / 64, Me, d, w.pieces, w.ps_h, st));
     for (int i = 0; i < c.n_enc_layers; ++i) {
       if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
-      TRY(gram_gemm_bf16_ex(w.h, m->enc_wqkv[i], w.qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
-      TRY(gram_enc_self_attn(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, st));
-      TRY(gram_gemm_bf16_ex(w.attn, m->enc_wo[i], w.x, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(linear(w, w.h, w.ps_h, m->enc_wqkv[i], w.qkv, w.ps_qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
+      TRY(gram_enc_self_attn_split(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, w.pieces, w.ps_qkv, w.ps_attn, st));
+      TRY(linear(w, w.attn, w.ps_attn, m->enc_wo[i], w.x, w.ps_h, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
-      TRY(gram_gemm_bf16_ex(w.h, m->enc_wi[i], w.u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
-      TRY(gram_gemm_bf16_ex(w.u, m->enc_wo2[i], w.x, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(linear(w, w.h, w.ps_h, m->enc_wi[i], w.u, w.ps_u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
+      TRY(linear(w, w.u, w.ps_u, m->enc_wo2[i], w.x, w.ps_h, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
     }
   } else {
-  TRY(gram_embed_i64(c.embed_f32, ids, w.x, Me, d, st));
-  for (int i = 0; i < c.n_enc_layers; ++i) {
-    TRY(gram_rmsnorm_bf16(w.x, m->enc_ln1[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, st));
-    TRY(gram_gemm_bf16(w.h, m->enc_wqkv[i], w.qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, st));
-    TRY(gram_enc_self_attn(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, st));
-    TRY(gram_gemm_bf16(w.attn, m->enc_wo[i], w.x, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, st));
-    TRY(gram_rmsnorm_bf16(w.x, m->enc_ln2[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, st));
-    TRY(gram_gemm_bf16(w.h, m->enc_wi[i], w.u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, st));
-    TRY(gram_gemm_bf16(w.u, m->enc_wo2[i], w.x, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, st));
-  }
+    TRY(gram_embed_i64(c.embed_f32, ids, w.x, Me, d, st));
+    for (int i = 0; i < c.n_enc_layers; ++i) {
+      TRY(gram_rmsnorm_bf16_split(w.x, m->enc_ln1[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, nullptr, w.pieces, w.ps_h, st));
+      TRY(linear(w, w.h, w.ps_h, m->enc_wqkv[i], w.qkv, w.ps_qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, nullptr, st));
+      TRY(gram_enc_self_attn_split(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, w.pieces, w.ps_qkv, w.ps_attn, st));
+      TRY(linear(w, w.attn, w.ps_attn, m->enc_wo[i], w.x, 0, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
+      TRY(gram_rmsnorm_bf16_split(w.x, m->enc_ln2[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, nullptr, w.pieces, w.ps_h, st));
+      TRY(linear(w, w.h, w.ps_h, m->enc_wi[i], w.u, w.ps_u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, nullptr, st));
+      TRY(linear(w, w.u, w.ps_u, m->enc_wo2[i], w.x, 0, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
+    }
   }
   return 0;
 }
@@ -198,11 +222,11 @@ int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const ui
   if (cached.n > 0) TRY(gram_gather_passage_x(cached.x, cached.slot, w.x + (size_t)Pe * L * d, cached.n, L, cached.cache_L, d, st));
   // final norm + per-passage position embedding = the late fusion (gram.py:238-255); the
   // (B*N, L, d) -> (B, N*L, d) view is free: rows are already user-major.
-  TRY(gram_rmsnorm_bf16_map(w.x, c.enc_final_ln, w.h, Me, d, c.eps, 1.f, c.use_position_embedding ? c.pos_emb_f32 : nullptr, N, L,
-                            pmap, st));
+  TRY(gram_rmsnorm_bf16_split(w.x, c.enc_final_ln, w.h, Me, d, c.eps, 1.f, c.use_position_embedding ? c.pos_emb_f32 : nullptr, N, L,
+                              pmap, w.pieces, w.ps_h, st));
   // every decoder layer's cross K/V in ONE GEMM, scattered into the beam-shared bank
   gram_kv_bank_t bank{w.bank_k, w.bank_vt, c.n_dec_layers, B, H, N * L, pmap, N, L};
-  TRY(gram_gemm_bf16(w.h, c.dec_wkv_x_all, nullptr, Me, c.n_dec_layers * 2 * inner, d, d, 0, GRAM_EPI_KV_BANK, &bank, st));
+  TRY(linear(w, w.h, w.ps_h, c.dec_wkv_x_all, nullptr, w.ps_bank, Me, c.n_dec_layers * 2 * inner, d, d, 0, GRAM_EPI_KV_BANK, &bank, nullptr, st));
   return 0;
 }
 
@@ -220,16 +244,14 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   const int d = c.d_model, inner = c.n_heads * 64, F = c.d_ff, H = c.n_heads, V = c.vocab;
   const int R = live ? live->n_rows : B * K, S = N * L;
   auto self_attn = [&](int i, size_t cache_layer) {
-    return live ? gram_dec_self_attn_live(w.qkvd, w.kcache + i * cache_layer, w.vcache + i * cache_layer, anc, c.dec_bias_f32,
-                                          w.attnd, R_cache, R, live->rows, H, t, Tmax, st)
-                : gram_dec_self_attn(w.qkvd, w.kcache + i * cache_layer, w.vcache + i * cache_layer, anc, c.dec_bias_f32, w.attnd,
-                                     R, H, t, Tmax, st);
+    return gram_dec_self_attn_split(w.qkvd, w.kcache + i * cache_layer, w.vcache + i * cache_layer, anc, c.dec_bias_f32, w.attnd,
+                                    live ? R_cache : R, R, live ? live->rows : nullptr, H, t, Tmax, w.pieces, w.ps_qkvd, w.ps_cache,
+                                    w.ps_attnd, st);
   };
   auto cross_attn = [&](int i, size_t bank_layer) {
-    return live ? gram_cross_attn_decode_live(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd,
-                                              live->n_users, live->users, live->rowpos, K, H, S, st)
-                : gram_cross_attn_decode(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd, B, K, H, S,
-                                         st);
+    return gram_cross_attn_decode_split(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd,
+                                        live ? live->n_users : B, K, H, S, live ? live->users : nullptr, live ? live->rowpos : nullptr,
+                                        w.pieces, w.ps_qx, w.ps_bank, w.ps_attnd, st);
   };
   const size_t bank_layer = (size_t)B * H * S * 64;
   const size_t cache_layer = (size_t)Tmax * R_cache * inner;
@@ -238,53 +260,72 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
     const bool pre_rs = R >= kPrecomputedRsRows;  // see encoder_layers
     const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rsd, 0, d, c.eps}
                                               : gram_norm_fusion_t{nullptr, nullptr, w.ssd, d / 64, d, c.eps};
-    TRY(gram_embed_ex(c.embed_f32, tokens, 0, w.xd, w.hd, w.ssd, d / 64, R, d, st));
+    TRY(gram_embed_ex_split(c.embed_f32, tokens, 0, w.xd, w.hd, w.ssd, d / 64, R, d, w.pieces, w.ps_hd, st));
     for (int i = 0; i < c.n_dec_layers; ++i) {
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
-      TRY(gram_gemm_bf16_ex(w.hd, m->dec_wqkv[i], w.qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
+      TRY(linear(w, w.hd, w.ps_hd, m->dec_wqkv[i], w.qkvd, w.ps_qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
       TRY(self_attn(i, cache_layer));
-      TRY(gram_gemm_bf16_ex(w.attnd, m->dec_wo[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo[i], w.xd, w.ps_hd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
-      TRY(gram_gemm_bf16_ex(w.hd, m->dec_wq_x[i], w.qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, &consume, st));
+      TRY(linear(w, w.hd, w.ps_hd, m->dec_wq_x[i], w.qx, w.ps_qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, &consume, st));
       TRY(cross_attn(i, bank_layer));
-      TRY(gram_gemm_bf16_ex(w.attnd, m->dec_wo_x[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo_x[i], w.xd, w.ps_hd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
-      TRY(gram_gemm_bf16_ex(w.hd, m->dec_wi[i], w.ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
-      TRY(gram_gemm_bf16_ex(w.ud, m->dec_wo2[i], w.xd, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(linear(w, w.hd, w.ps_hd, m->dec_wi[i], w.ud, w.ps_ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
+      TRY(linear(w, w.ud, w.ps_ud, m->dec_wo2[i], w.xd, w.ps_hd, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
     }
   } else {
-  TRY(gram_embed_i32(c.embed_f32, tokens, w.xd, R, d, st));
-  for (int i = 0; i < c.n_dec_layers; ++i) {
-    TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln1[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
-    TRY(gram_gemm_bf16(w.hd, m->dec_wqkv[i], w.qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, st));
-    TRY(self_attn(i, cache_layer));
-    TRY(gram_gemm_bf16(w.attnd, m->dec_wo[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, st));
-    TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln2[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
-    TRY(gram_gemm_bf16(w.hd, m->dec_wq_x[i], w.qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, st));
-    TRY(cross_attn(i, bank_layer));
-    TRY(gram_gemm_bf16(w.attnd, m->dec_wo_x[i], w.xd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, st));
-    TRY(gram_rmsnorm_bf16(w.xd, m->dec_ln3[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, st));
-    TRY(gram_gemm_bf16(w.hd, m->dec_wi[i], w.ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, st));
-    TRY(gram_gemm_bf16(w.ud, m->dec_wo2[i], w.xd, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, st));
-  }
+    TRY(gram_embed_i32(c.embed_f32, tokens, w.xd, R, d, st));
+    for (int i = 0; i < c.n_dec_layers; ++i) {
+      TRY(gram_rmsnorm_bf16_split(w.xd, m->dec_ln1[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, nullptr, w.pieces, w.ps_hd, st));
+      TRY(linear(w, w.hd, w.ps_hd, m->dec_wqkv[i], w.qkvd, w.ps_qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, nullptr, st));
+      TRY(self_attn(i, cache_layer));
+      TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo[i], w.xd, 0, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
+      TRY(gram_rmsnorm_bf16_split(w.xd, m->dec_ln2[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, nullptr, w.pieces, w.ps_hd, st));
+      TRY(linear(w, w.hd, w.ps_hd, m->dec_wq_x[i], w.qx, w.ps_qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, nullptr, st));
+      TRY(cross_attn(i, bank_layer));
+      TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo_x[i], w.xd, 0, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
+      TRY(gram_rmsnorm_bf16_split(w.xd, m->dec_ln3[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, nullptr, w.pieces, w.ps_hd, st));
+      TRY(linear(w, w.hd, w.ps_hd, m->dec_wi[i], w.ud, w.ps_ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, nullptr, st));
+      TRY(linear(w, w.ud, w.ps_ud, m->dec_wo2[i], w.xd, 0, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
+    }
   }
   const float scale = c.tie_word_embeddings ? 1.0f / sqrtf((float)d) : 1.f;  // gram_t5.py:249-252
-  TRY(gram_rmsnorm_bf16(w.xd, c.dec_final_ln, w.hd, R, d, c.eps, scale, nullptr, 1, 1, st));
+  TRY(gram_rmsnorm_bf16_split(w.xd, c.dec_final_ln, w.hd, R, d, c.eps, scale, nullptr, 1, 1, nullptr, w.pieces, w.ps_hd, st));
+  const gram_split_t sp{w.pieces, w.ps_hd, 0, 0, 0};
   if (lse_part)  // log-softmax normaliser partials straight from the accumulators; logits may be NULL (not stored)
-    TRY(gram_gemm_bf16_lse(w.hd, c.lm_head_bf16, logits, lse_part, R, V, d, d, V, st));
+    TRY(gram_gemm_bf16_lse_split(w.hd, c.lm_head_bf16, logits, lse_part, R, V, d, d, V, &sp, st));
   else
-    TRY(gram_gemm_bf16(w.hd, c.lm_head_bf16, logits, R, V, d, d, V, GRAM_EPI_F32, nullptr, st));
+    TRY(gram_gemm_bf16_split(w.hd, c.lm_head_bf16, logits, R, V, d, d, V, GRAM_EPI_F32, nullptr, nullptr, &sp, st));
   return 0;
+}
+
+// the search step on the hidden states decode_step left in w.hd (rowpos: live-row step, else NULL)
+int search_step(const gram_model* m, const Workspace& w, const gram_trie_t* trie, int cur_len, int rows_per_user, const int32_t* rowpos,
+                void* st) {
+  const gram_model_desc_t& c = m->d;
+  if (w.pieces > 1)
+    return gram_beam_step_sparse_split(&w.beam, trie, w.hd, c.lm_head_f32, c.d_model, w.lse, c.vocab, cur_len, rows_per_user, rowpos,
+                                       w.pieces, w.ps_hd, st);
+  if (rowpos) return gram_beam_step_sparse_live(&w.beam, trie, w.hd, c.lm_head_bf16, c.d_model, w.lse, c.vocab, cur_len, rowpos, st);
+  return gram_beam_step_sparse(&w.beam, trie, w.hd, c.lm_head_bf16, c.d_model, w.lse, c.vocab, cur_len, rows_per_user, st);
 }
 
 }  // namespace
 
 extern "C" int gram_abi_version(void) { return GRAM_ABI_VERSION; }
 
+static int g_live_rows = -1;  // -1: the GRAM_LIVE_ROWS environment variable decides (default on)
+extern "C" int gram_debug_set_live_rows(int on) {
+  g_live_rows = on;
+  return 0;
+}
+
 extern "C" gram_model_t* gram_model_create(const gram_model_desc_t* d) {
   if (!d || d->vocab % 128 || d->d_model % 128 || d->d_ff % 128 || d->n_heads < 1 || d->n_heads > 16 ||
       (d->n_heads * 64) % 128 || d->d_model > 1024 || d->n_enc_layers < 1 || d->n_dec_layers < 1)
     return nullptr;
+  if (d->pieces < 0 || d->pieces > GRAM_MAX_PIECES || (d->pieces > 1 && !d->lm_head_f32)) return nullptr;
   gram_model* m = new gram_model();
   m->d = *d;
   auto cpf = [](std::vector<const float*>& v, const float* const* src, int n) { v.assign(src, src + n); };
@@ -337,8 +378,8 @@ extern "C" int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
   TRY(encode(m, w, input_ids, mask, B, N, L, B * N, nullptr, CachedPassages{0, 0, nullptr, nullptr}, stream));
-  if (enc_out_bf16) {
-    hipError_t e = hipMemcpyAsync(enc_out_bf16, w.h, (size_t)B * N * L * m->d.d_model * sizeof(bf16), hipMemcpyDeviceToDevice,
+  if (enc_out_bf16) {  // (split modes: all the pieces, [pieces][B*N*L][d])
+    hipError_t e = hipMemcpyAsync(enc_out_bf16, w.h, (size_t)w.pieces * B * N * L * m->d.d_model * sizeof(bf16), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
@@ -403,10 +444,11 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
     }
     TRY(gram_greedy_finalize(&w.beam, max_length, sequences, w.width, stream));
   } else {
-  static const bool live_rows = [] {
+  static const bool live_rows_env = [] {
     const char* e = getenv("GRAM_LIVE_ROWS");
     return !(e && e[0] == '0');
   }();
+  const bool live_rows = g_live_rows < 0 ? live_rows_env : g_live_rows != 0;
   // fixed max_length-1 steps: finished users are padded exactly as BeamSearchScorer.process
   // pads them, so skipping HF's all-done early exit changes nothing and needs no host sync
   for (int t = 0; t + 1 < max_length; ++t) {
@@ -431,8 +473,7 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
                           stream));
           TRY(gram_lse_combine(w.lse_part, w.lse, counts[0], m->d.vocab / 64, stream));
         }  // else: no beam can be extended; the search step below reads no decoder row
-        TRY(gram_beam_step_sparse_live(&w.beam, trie, w.hd, m->d.lm_head_bf16, m->d.d_model, w.lse, m->d.vocab, t + 1,
-                                       w.live.rowpos, stream));
+        TRY(search_step(m, w, trie, t + 1, K, w.live.rowpos, stream));
         continue;
       }
     }
@@ -440,7 +481,7 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
     TRY(decode_step(m, w, w.beam.tokens, w.beam.anc, mask, B, N, L, Kt, B * K, max_length, t, nullptr, w.lse_part, nullptr,
                     stream));
     TRY(gram_lse_combine(w.lse_part, w.lse, B * Kt, m->d.vocab / 64, stream));
-    TRY(gram_beam_step_sparse(&w.beam, trie, w.hd, m->d.lm_head_bf16, m->d.d_model, w.lse, m->d.vocab, t + 1, Kt, stream));
+    TRY(search_step(m, w, trie, t + 1, Kt, nullptr, stream));
   }
   TRY(gram_beam_finalize(&w.beam, nret, max_length, sequences, scores, w.width, stream));
   }

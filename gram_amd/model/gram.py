@@ -174,7 +174,10 @@ class GRAM(nn.Module):
             remapped[k] = v
         return self.load_state_dict(remapped, strict=False)
 
-    PRECISIONS = ("bf16",)
+    # "bf16": bf16 operands (8 significant bits).  "bf16x3" / "bf16x6": every value travels as 2 / 3 bf16 pieces and every
+    # product is 3 / 6 bf16 MFMA products (gram_hip.h, gram_split_t): ~2^-18 / fp32-class relative error at 3x / 6x the MFMA work.
+    PRECISIONS = ("bf16", "bf16x3", "bf16x6")
+    _PIECES = {"bf16": 1, "bf16x3": 2, "bf16x6": 3}
 
     def set_precision(self, mode: str) -> None:
         """Arithmetic of the GEMM / attention operands (accumulation, residual stream, softmax and scores are fp32 in
@@ -241,8 +244,20 @@ class GRAM(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
+        pieces = self._PIECES[self._precision]
+
         def b16(t):
-            t = t.to(dev, torch.float32).to(torch.bfloat16).contiguous()
+            """[out][in] fp32 -> the MFMA weight operand: bf16, or (split modes) the product-expanded [out][nprod*in] matrix
+            whose chunk c holds piece SPLIT_W_PIECE[c] of W = p0 + p1 (+ p2), p_i = bf16(W - p0 - .. - p_{i-1})."""
+            t = t.to(dev, torch.float32)
+            if pieces == 1:
+                t = t.to(torch.bfloat16).contiguous()
+            else:
+                ps, r = [], t.clone()
+                for _ in range(pieces):
+                    ps.append(r.to(torch.bfloat16))
+                    r -= ps[-1].float()
+                t = torch.cat([ps[j] for j in _lib.SPLIT_W_PIECE[pieces]], dim=1).contiguous()
             keep.append(t)
             return t.data_ptr()
 
@@ -254,7 +269,7 @@ class GRAM(nn.Module):
         # T5LayerNorm folding (gram_norm_fusion_t): the gain g of the norm in front of a Linear is folded into
         # that Linear's columns (W[n][k] * g[k], in fp32, then one bf16 rounding); the 1/rms factor is applied
         # per row in the GEMM epilogue.  GRAM_FOLD_NORM=0 keeps the separate norm kernels (A/B, debugging).
-        fold = os.environ.get("GRAM_FOLD_NORM", "1") != "0"
+        fold = os.environ.get("GRAM_FOLD_NORM", "1") != "0" or pieces > 1
 
         def lin(wname, gname):
             w = sd[wname].to(dev, torch.float32)
@@ -304,6 +319,7 @@ class GRAM(nn.Module):
             dec_wi=ptr_array([lin(dd.format(i) + ".2.DenseReluDense.wi.weight", dd.format(i) + ".2.layer_norm.weight") for i in range(nd)]),
             dec_wo2=ptr_array([b16(sd[dd.format(i) + ".2.DenseReluDense.wo.weight"]) for i in range(nd)]),
             dec_wkv_x_all=b16(wkv_all),
+            pieces=pieces, lm_head_f32=f32(sd["lm_head.weight"]) if pieces > 1 else None,
         )
         handle = lib.gram_model_create(C.byref(desc))
         if not handle:
@@ -473,6 +489,18 @@ class GRAM(nn.Module):
         0-padded, starting with the decoder start token -- and ``sequences_scores`` (fp32)."""
         if prefix_allowed_tokens_fn is None:
             raise NotImplementedError("unconstrained generation is not on GRAM's scoring path (a Trie is always passed)")
+        # HF kwargs that would change the search: refuse the ones this path does not implement instead of ignoring them
+        neutral = {"do_sample": False, "early_stopping": False, "num_beam_groups": 1, "repetition_penalty": 1.0,
+                   "no_repeat_ngram_size": 0, "diversity_penalty": 0.0, "use_cache": True, "temperature": 1.0, "top_k": 50,
+                   "top_p": 1.0, "min_length": 0, "pad_token_id": 0, "eos_token_id": 1, "decoder_start_token_id": 0}
+        for k, v in unused.items():
+            if k in neutral:
+                if v is not None and v != neutral[k] and k not in ("temperature", "top_k", "top_p"):
+                    raise NotImplementedError(f"generate({k}={v!r}) is not supported by the HIP scoring path "
+                                              f"(only {k}={neutral[k]!r}, the value the GRAM runners use)")
+            elif v is not None:
+                import warnings
+                warnings.warn(f"gram_amd.GRAM.generate ignores the keyword argument {k!r}")
         if input_ids.dim() != 3:
             raise ValueError("input_ids must be (B, N, L)")
         handle = self._pack()

@@ -42,6 +42,56 @@ class BaseRunner:
         self.validloaders: List = [valid_loader] if valid_loader is not None else []
         self.cur_model_path = None
         self.last_results = None
+        # single_runner_gram.py:46,51 / distributed_runner_gram.py:57-66: the runner builds its own test and validation
+        # loaders at construction.  An args namespace without --datasets (unit tests driving test_dataset_task with
+        # their own loader) skips that; test()/validate() then raise instead of silently scoring nothing.
+        if _arg(args, "datasets", None) and _arg(args, "data_path", None):
+            self.get_testloader(regenerate=False, phase=0)
+            self.get_validloader(regenerate=False, phase=0)
+
+    # ---------------------------------------------------------------- loaders
+    def _make_dataset(self, dataset, task, model_gen, tokenizer, regenerate, phase, debug_test_small_set, mode):
+        from ..data import TestDatasetGRAM
+        return TestDatasetGRAM(self.args, dataset, task, model_gen, tokenizer, regenerate, phase,
+                               debug_test_small_set=debug_test_small_set, mode=mode)
+
+    def _make_loader(self, data, collator):
+        """single_runner_gram.py:320-325: batch_size = --eval_batch_size, no shuffling, num_workers 0."""
+        from torch.utils.data import DataLoader
+        return DataLoader(dataset=data, batch_size=int(_arg(self.args, "eval_batch_size", 1)), collate_fn=collator, shuffle=False)
+
+    def _build_loaders(self, mode, model_gen, tokenizer, regenerate, phase, debug_test_small_set):
+        from ..processor import CollatorGRAM
+        if not _arg(self.args, "datasets", None):
+            raise ValueError("args.datasets is empty: there is nothing to build an evaluation loader from")
+        collator = CollatorGRAM(self.tokenizer, args=self.args, mode="test" if mode == "test" else "valid")
+        loaders = []
+        for dataset in self.args.datasets.split(","):
+            for task in _arg(self.args, "tasks", "sequential").split(","):
+                data = self._make_dataset(dataset, task, model_gen, tokenizer, regenerate, phase, debug_test_small_set, mode)
+                loaders.append(self._make_loader(data, collator))
+        return loaders
+
+    def get_testloader(self, model_gen=None, tokenizer=None, regenerate=False, phase=0, debug_test_small_set=False):
+        """single_runner_gram.py:296-326 (distributed: :300-359): one loader per (dataset, task), test hold-out."""
+        self.testloaders = self._build_loaders("test", model_gen, tokenizer, regenerate, phase, debug_test_small_set)
+
+    def get_validloader(self, model_gen=None, tokenizer=None, regenerate=False, phase=0, debug_test_small_set=False):
+        """single_runner_gram.py:328-358: the same with mode="validation" (second-to-last item held out)."""
+        self.validloaders = self._build_loaders("validation", model_gen, tokenizer, regenerate, phase, debug_test_small_set)
+
+    def _loaders_for(self, mode):
+        """test()/validate() rebuild their loaders like the reference (single_runner_gram.py:370-375,408-413) when the
+        args describe a dataset; otherwise they use what the caller put in testloaders/validloaders -- and an empty list
+        is an error, never a silent no-op."""
+        if _arg(self.args, "datasets", None) and _arg(self.args, "data_path", None):
+            small = bool(_arg(self.args, "debug_test_small_set", False))
+            (self.get_testloader if mode == "test" else self.get_validloader)(regenerate=False, phase=0, debug_test_small_set=small)
+        loaders = self.testloaders if mode == "test" else self.validloaders
+        if not loaders:
+            raise RuntimeError(f"no {mode} loader: pass args.datasets/args.data_path (the reference's flags) or fill "
+                               f"runner.{'testloaders' if mode == 'test' else 'validloaders'} before calling")
+        return loaders
 
     # ---------------------------------------------------------------- candidates -> Trie
     def encode_candidates(self, candidates: Sequence) -> List[List[int]]:
@@ -105,7 +155,14 @@ class BaseRunner:
         encoded = self.encode_candidates(candidates)
         trie = gt.Trie(encoded)
         fn = gt.prefix_allowed_tokens_fn(trie)
-        max_length = max(len(c) for c in encoded)  # single_runner_gram.py:633-636, hoisted out of the loop
+        # single_runner_gram.py:633-641, hoisted out of the loop: the longest candidate for the "t5_token" / "split" id types,
+        # 50 for the others.  Every candidate of those other types ends with the tokenizer's EOS, so all beams are finished
+        # by the Trie's depth and HF leaves the loop there: clamping 50 to that depth returns the same sequences and scores.
+        max_length = max(len(c) for c in encoded)
+        if isinstance(candidates[0], str) and _arg(self.args, "item_id_type", "split") not in ("t5_token", "split"):
+            if max_length > 50 or not all(c[-1] == 1 for c in encoded):
+                raise ValueError("item_id_type %r: candidates must end with EOS and fit in max_length=50 (single_runner_gram.py:641)"
+                                 % _arg(self.args, "item_id_type", None))
         K = self.generate_num
         model = self._generate_model()
         ranks, user_ids, examples, total_time = [], [], [], 0.0
@@ -154,27 +211,35 @@ class BaseRunner:
                     f.write(f"{name}: {val}\n")
 
     def test_from_model(self, rec_model_path=None, id_model_path=None):
+        """single_runner_gram.py:359-368: the loaders built at construction, non-strict load."""
         self.model.eval()
         self._load(rec_model_path, strict=False)
+        if not self.testloaders:
+            raise RuntimeError("no test loader (see get_testloader)")
         for loader in self.testloaders:
             self.test_dataset_task(loader)
 
-    def test(self, path=None):
+    def test(self, path=None, debug_test_small_set=False):
+        """single_runner_gram.py:370-393 / distributed_runner_gram.py:425-443 (debug_test_on_train is a training-set
+        diagnostic and stays out of this build)."""
+        loaders = self._loaders_for("test")
         self.model.eval()
         self._load(path)
-        for loader in self.testloaders:
+        for loader in loaders:
             self.test_dataset_task(loader)
 
     def validate_from_model(self, rec_model_path=None, id_model_path=None):
+        loaders = self._loaders_for("validation")
         self.model.eval()
         self._load(rec_model_path, strict=False)
-        for loader in self.validloaders:
+        for loader in loaders:
             self.test_dataset_task(loader, mode="validation")
 
-    def validate(self, path=None):
+    def validate(self, path=None, debug_test_small_set=False):
+        loaders = self._loaders_for("validation")
         self.model.eval()
         self._load(path)
-        for loader in self.validloaders:
+        for loader in loaders:
             self.test_dataset_task(loader, mode="validation")
 
     def train_generator(self):

@@ -51,10 +51,46 @@ def all_gather_hit_ranks(ranks: np.ndarray, device, group=None) -> np.ndarray:
     return got[got != -2].astype(np.int16)
 
 
+class ShardSampler(torch.utils.data.Sampler):
+    """This rank's user indices.  Default: ``shard_indices`` (strided, every user exactly once over the ranks); with
+    ``--eval_pad_like_reference 1`` the order and padding of the reference's ``DistributedSampler(testdata)``
+    (distributed_runner_gram.py:351: shuffled with seed 0, repeated up to ceil(n/W)*W, the duplicates counted)."""
+
+    def __init__(self, n, world, rank, pad_like_reference=False):
+        self.indices = shard_indices(n, world, rank, pad_like_reference)
+
+    def __iter__(self):
+        return iter(self.indices)
+
+    def __len__(self):
+        return len(self.indices)
+
+
 class DistributedRunnerGRAM(BaseRunner):
     def __init__(self, model_rec, model_gen, tokenizer, train_loader_id, train_loader_rec, valid_loader, device, args, rank=0):
+        self.rank = rank  # (before the base constructor: it builds the loaders, which shard by rank)
         super().__init__(model_rec, model_gen, tokenizer, train_loader_id, train_loader_rec, valid_loader, device, args)
-        self.rank = rank
+
+    def _make_dataset(self, dataset, task, model_gen, tokenizer, regenerate, phase, debug_test_small_set, mode):
+        """distributed_runner_gram.py:313-336: rank 0 builds the dataset first (it may regenerate the item-id file), the
+        others wait at the barrier and then read what rank 0 wrote, never regenerating."""
+        build = super()._make_dataset
+        if not (dist.is_available() and dist.is_initialized()):
+            return build(dataset, task, model_gen, tokenizer, regenerate, phase, debug_test_small_set, mode)
+        if self.rank == 0:
+            data = build(dataset, task, model_gen, tokenizer, regenerate, phase, debug_test_small_set, mode)
+            dist.barrier()
+        else:
+            dist.barrier()
+            data = build(dataset, task, model_gen, tokenizer, False, phase, debug_test_small_set, mode)
+        return data
+
+    def _make_loader(self, data, collator):
+        from torch.utils.data import DataLoader
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        sampler = ShardSampler(len(data), world, self.rank, bool(int(_arg(self.args, "eval_pad_like_reference", 0))))
+        return DataLoader(dataset=data, sampler=sampler, batch_size=int(_arg(self.args, "eval_batch_size", 1)), collate_fn=collator,
+                          shuffle=False)
 
     def test_dataset_task(self, testloader, mode="test"):
         if self.rank == 0:

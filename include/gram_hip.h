@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GRAM_ABI_VERSION 2
+#define GRAM_ABI_VERSION 3
 
 #define GRAM_E_ARG (-1)       /* bad shape / unsupported size                           */
 #define GRAM_E_WORKSPACE (-2) /* workspace too small (see gram_workspace_bytes)          */
@@ -89,6 +89,54 @@ int gram_row_rscale(const float* ss, float* rs, int M, int nblk, int d, float ep
 int gram_embed_ex(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk, int rows,
                   int d, void* stream);
 
+/* ---- split-bf16 operands: fp32-class arithmetic on the bf16 MFMA ("bf16x3", "bf16x6") --------------------
+ * The reference computes in fp32 end to end (no autocast / half anywhere in src/; fp32 softmax gram_t5_modeling.py:608).
+ * Plain bf16 operands carry 8 significant bits, which moves Recall@5/NDCG@5 by ~5e-3 on a 2 048-user population
+ * (profiles/r02_precision_*.json) -- 50x the 1e-4 bound.  In the split modes a value v travels as `pieces` bf16 numbers
+ *     p0 = bf16(v),  p1 = bf16(v - p0),  p2 = bf16(v - p0 - p1)
+ * and a product a*w is evaluated on the bf16 MFMA as the sum of piece products, accumulated in fp32 smallest first:
+ *     pieces = 2:  a0*w1 + a1*w0 + a0*w0                              3 MFMAs, relative error ~2^-18
+ *     pieces = 3:  a0*w2 + a2*w0 + a1*w1 + a1*w0 + a0*w1 + a0*w0      6 MFMAs, ~2^-26 (below fp32's own rounding)
+ * Layouts: every bf16 buffer (activations, Q/K/V, the KV bank, the self-attention cache) becomes `pieces` copies of its
+ * plain layout, piece p starting `pstride` elements after piece p - 1.  A weight matrix [N][kc] is expanded on the host to
+ * [N][nprod * kc]: chunk c (columns [c*kc, (c+1)*kc)) holds W piece GRAM_SPLIT_W_PIECE[pieces][c] and meets A piece
+ * GRAM_SPLIT_A_PIECE[pieces][c].  pieces = 1 is the plain bf16 path (all *_split entry points accept split = NULL). */
+#define GRAM_MAX_PIECES 3
+static const int GRAM_SPLIT_NPROD[GRAM_MAX_PIECES + 1] = {0, 1, 3, 6};
+static const int GRAM_SPLIT_A_PIECE[GRAM_MAX_PIECES + 1][6] = {{0}, {0}, {0, 1, 0}, {0, 2, 1, 1, 0, 0}};
+static const int GRAM_SPLIT_W_PIECE[GRAM_MAX_PIECES + 1][6] = {{0}, {0}, {1, 0, 0}, {2, 0, 1, 0, 1, 0}};
+typedef struct {
+  int32_t pieces;       /* 1 .. GRAM_MAX_PIECES                                                     */
+  int64_t a_pstride;    /* elements between the pieces of A                                         */
+  int64_t c_pstride;    /* ... of a bf16 C (GRAM_EPI_BF16, GRAM_EPI_BF16_RELU)                      */
+  int64_t xb_pstride;   /* ... of gram_norm_fusion_t.xb_out                                         */
+  int64_t bank_pstride; /* ... of gram_kv_bank_t.k and .vt                                          */
+} gram_split_t;
+/* gram_gemm_bf16_ex on split operands: A is `pieces` copies of [M][lda], W the expanded [N][nprod*kc] matrix, kc the
+ * LOGICAL reduction length; bf16 results are written as pieces, fp32 results (residual stream, logits, LSE) as fp32. */
+int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M, int N, int kc, int lda, int ldc, int epilogue,
+                         const gram_kv_bank_t* bank_host, const gram_norm_fusion_t* nf_host, const gram_split_t* split_host,
+                         void* stream);
+int gram_gemm_bf16_lse_split(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int kc, int lda,
+                             int ldc, const gram_split_t* split_host, void* stream);
+
+/* The other kernels on split operands.  Every bf16 input/output is `pieces` copies of the plain layout, *_pstride
+ * elements apart; masks, bias tables, fp32 tensors and integer state are as in the plain entry points. */
+int gram_embed_ex_split(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk, int rows,
+                        int d, int pieces, int64_t xb_pstride, void* stream);
+int gram_rmsnorm_bf16_split(const float* x, const float* w, void* out_bf16, int rows, int d, float eps, float scale,
+                            const float* pos, int N, int L, const int32_t* passage_map, int pieces, int64_t out_pstride,
+                            void* stream);
+int gram_enc_self_attn_split(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H,
+                             int pieces, int64_t qkv_pstride, int64_t out_pstride, void* stream);
+/* users/rowpos NULL: all B users, rows b*K + beam; else the live-row form (gram_cross_attn_decode_live, B = n_users). */
+int gram_cross_attn_decode_split(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out, int B,
+                                 int K, int H, int S, const int32_t* users, const int32_t* rowpos, int pieces,
+                                 int64_t q_pstride, int64_t bank_pstride, int64_t out_pstride, void* stream);
+/* rows NULL: all R rows; else the live-row form (gram_dec_self_attn_live). */
+int gram_dec_self_attn_split(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias, void* out,
+                             int R, int n_rows, const int32_t* rows, int H, int t, int Tmax, int pieces, int64_t qkv_pstride,
+                             int64_t cache_pstride, int64_t out_pstride, void* stream);
 /* lm_head with the log-softmax normaliser fused: logits as GRAM_EPI_F32, plus for every row and every
  * 64-column block the pair (max, sum exp(x - max)) in lse_part f32 [M][N/64][2]; gram_lse_combine folds
  * them into lse[M] = log sum_v exp(logits[m][v]) without re-reading the logits (gram_row_lse does).
@@ -220,6 +268,12 @@ int gram_beam_step_sparse_live(const gram_beam_state_t* st_host, const gram_trie
                                const void* lm_head_bf16, int d, const float* lse, int V, int cur_len,
                                const int32_t* rowpos, void* stream);
 
+/* gram_beam_step_sparse[_live] with the hidden state as pieces: the allowed logits are h . E[tok] in fp32, h the fp32 sum
+ * of the pieces and E the FP32 lm_head table [V][d] (rowpos NULL: rows b*K + beam, rows_per_user as in gram_beam_step). */
+int gram_beam_step_sparse_split(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const void* hidden_bf16,
+                                const float* lm_head_f32, int d, const float* lse, int V, int cur_len, int rows_per_user,
+                                const int32_t* rowpos, int pieces, int64_t hidden_pstride, void* stream);
+
 /* HF 4.26 greedy_search (generate with num_beams == 1; BASELINE configs[0]) on the same state with K = 1:
  * argmax of the RAW logits over the Trie children (first maximum), finished users emit pad; finalize copies
  * the sequences (i64 [B][max_length]) and reports the width HF would return (it stops once all rows hit EOS). */
@@ -263,6 +317,11 @@ typedef struct {
   const void* const* dec_wi;   /* [n_dec]  bf16 [d_ff][d]                                  */
   const void* const* dec_wo2;  /* [n_dec]  bf16 [d][d_ff]                                  */
   const void* dec_wkv_x_all;   /* bf16 [n_dec*2*inner][d]: per layer k rows then v rows     */
+  /* split-bf16 precision modes (gram_split_t): pieces = 2 ("bf16x3") or 3 ("bf16x6"); 0 / 1 = plain bf16.  Then EVERY bf16
+   * weight above is the product-expanded matrix [out][nprod * in] and lm_head_f32 [V][d] must be given too (the beam
+   * kernel's sparse logits).  fold_norm must be 1. */
+  int32_t pieces;
+  const float* lm_head_f32;
 } gram_model_desc_t;
 
 typedef struct gram_model gram_model_t;
@@ -364,6 +423,10 @@ int gram_debug_set_gemm_variant(int variant);
 /* Calibration probe (bench.py): one streaming read of `bytes` (16-B aligned) through every CU; nothing is
  * written unless a 32-bit fold of the data hits one magic value (sink may be NULL). */
 int gram_debug_stream_read(const void* src, size_t bytes, void* sink, void* stream);
+
+/* A/B hook (bench.py): 0 = decode every row in every step like the reference, 1 = live-row compaction (gram_live_rows_t),
+ * -1 = what the GRAM_LIVE_ROWS environment variable says (default 1).  Results are bit-identical either way. */
+int gram_debug_set_live_rows(int on);
 
 int gram_abi_version(void);
 

@@ -26,12 +26,13 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_struct_sizes():
     lib = _lib.load()
-    assert lib.gram_abi_version() == 2
+    assert lib.gram_abi_version() == _lib.ABI_VERSION == 3
     # field layout sanity (pointer + int32 packing as in the C header)
     assert ctypes.sizeof(_lib.KVBank) == 48
     assert ctypes.sizeof(_lib.Trie) == 40
     assert ctypes.sizeof(_lib.BeamState) == 24 + 12 * 8
-    assert ctypes.sizeof(_lib.ModelDesc) == 48 + 7 * 8 + 15 * 8 + 8
+    assert ctypes.sizeof(_lib.ModelDesc) == 48 + 7 * 8 + 15 * 8 + 8 + 16
+    assert ctypes.sizeof(_lib.Split) == 40
 
 
 def test_argument_errors_without_gpu():

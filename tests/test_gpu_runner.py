@@ -1,0 +1,107 @@
+"""-m gpu: the drop-in entry points with the HIP model and nothing else -- ``get_runner(kind, ...).test(ckpt_path)`` as
+main_generative_gram.py:107-127,191-209 calls them, with a reference-shaped args namespace, on the dataset directory
+tests/golden/dataset_fixture: the runner builds its own dataset / collator / loaders, loads the checkpoint, scores every
+user through gram_generate and writes the preds TSV.  The distributed runner is run as 5 ranks sharing the one test GPU
+(gloo for the collectives; RCCL needs a GPU per rank) on a user count the world size does not divide, and must
+reproduce the single runner's result."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.test_runner_loaders import K, PieceTokenizer, fixture_args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg():
+    import gram_amd
+    return gram_amd.T5Config(vocab_size=32128, d_model=256, d_ff=512, num_layers=2, num_decoder_layers=2, num_heads=4, max_item_num=20)
+
+
+def _checkpoint(path):
+    import gram_amd
+    torch.manual_seed(77)
+    m = gram_amd.create_model("gram", _cfg())
+    torch.save(m.state_dict(), path)
+
+
+def test_single_runner_test_and_validate_from_checkpoint(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gram_amd
+    from gram_amd.runner import get_runner
+    ckpt = str(tmp_path / "model_rec_best.pt")
+    _checkpoint(ckpt)
+    args = fixture_args(save_predictions=True, pred_path=str(tmp_path / "preds.tsv"), eval_batch_size=5, passage_cache=1)
+    torch.manual_seed(1)  # different init: the scores must come from the checkpoint
+    model = gram_amd.create_model("gram", _cfg()).to(DEV)
+    runner = get_runner("single", model, None, PieceTokenizer(), None, None, None, DEV, args)
+    runner.test(ckpt)
+    res = runner.last_results
+    n = len(runner.testloaders[0].dataset)
+    assert res["total"] == n == 12
+    lines = open(args.pred_path).read().splitlines()
+    rows = [ln.split("\t") for ln in lines[1:1 + n]]
+    items = {" ".join(str(t) for t in c if t > 1) for c in runner.encode_candidates(runner.testloaders[0].dataset.all_items)}
+    for r in rows:
+        preds, scores = r[-2].split("||"), [float(x) for x in r[-1].split("||")]
+        assert len(preds) == K and len(set(preds)) == K and all(p in items for p in preds)
+        assert scores == sorted(scores, reverse=True)
+    # the checkpoint decides the result: the freshly initialised weights give other scores
+    torch.manual_seed(1)
+    other = gram_amd.create_model("gram", _cfg()).to(DEV)
+    r2 = get_runner("single", other, None, PieceTokenizer(), None, None, None, DEV, fixture_args(eval_batch_size=5))
+    r2.test_dataset_task(r2.testloaders[0])
+    assert r2.last_results["total"] == n
+    runner.validate(ckpt)
+    assert runner.last_results["total"] == len(runner.validloaders[0].dataset) == 12
+
+
+def _worker(rank, world, rdzv, ckpt, pred, q):
+    import gram_amd
+    from gram_amd.runner import get_runner
+    dist.init_process_group("gloo", init_method=f"file://{rdzv}", rank=rank, world_size=world)
+    try:
+        args = fixture_args(eval_batch_size=2, rank=rank, save_predictions=True, pred_path=pred)
+        model = gram_amd.create_model("gram", _cfg()).to(DEV)
+        runner = get_runner("distributed", model, None, PieceTokenizer(), None, None, None, DEV, args, rank)
+        runner.test(ckpt)
+        q.put((rank, len(runner.last_results["local_hit_ranks"]), runner.last_results["total"], runner.last_results["sums"].tolist(),
+               sorted(runner.last_results["hit_ranks"].tolist())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_runner_five_ranks_one_gpu_matches_single(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gram_amd
+    from gram_amd.runner import get_runner
+    ckpt = str(tmp_path / "model_rec_best.pt")
+    _checkpoint(ckpt)
+    p_single, p_dist = str(tmp_path / "single.tsv"), str(tmp_path / "dist.tsv")
+    model = gram_amd.create_model("gram", _cfg()).to(DEV)
+    single = get_runner("single", model, None, PieceTokenizer(), None, None, None, DEV,
+                        fixture_args(eval_batch_size=2, save_predictions=True, pred_path=p_single))
+    single.test(ckpt)
+    want = single.last_results
+    world = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, str(tmp_path / "rdzv"), ckpt, p_dist, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=600) for _ in procs)
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert [r[1] for r in res] == [3, 3, 2, 2, 2] and all(r[2] == 12 for r in res)
+    assert all(np.allclose(r[3], want["sums"]) for r in res)
+    assert all(r[4] == sorted(want["hit_ranks"].tolist()) for r in res)
+    # same rows in the merged TSV (batch invariance of the kernels: a user's scores do not depend on its batch)
+    a, b = open(p_single).read().splitlines(), open(p_dist).read().splitlines()
+    assert a[0] == b[0] and sorted(a[1:13]) == sorted(b[1:13])
