@@ -660,6 +660,8 @@ struct PPOut {
   uint32_t ldx_b;   // ldc * 2
   uint32_t ss_nblk;
   int rows;
+  int split;            // bf16 pieces written (gram_split_t); piece p is c_ps_b / xb_ps_b bytes after piece p - 1
+  long c_ps_b, xb_ps_b;
 };
 template <int EPI, bool FULL, int SMODE = 0>
 __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, char* patch, const PPOut& o, int lane_, const float* rs) {
@@ -672,31 +674,39 @@ __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, c
   for (int jj = 0; jj < 2; ++jj) {
     const int j = j0 + jj;
     if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
-      // 16 rows x 64 cols bf16: patch[16][128 B], chunk c (16 B) at c ^ (row & 7)
+      // 16 rows x 64 cols bf16: patch[16][128 B], chunk c (16 B) at c ^ (row & 7); one pass per bf16 piece of the output
       const float sc = rs ? rs[j * 16 + r16] : 1.f;
+      f32x4 v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        f32x4 v = acc[i][j] * sc;
+        v[i] = acc[i][j] * sc;
         if constexpr (EPI == GRAM_EPI_BF16_RELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
         }
-        const int chunk = (i * 2 + (g >> 1)) ^ (r16 & 7);
-        *reinterpret_cast<uint2*>(patch + r16 * 128 + chunk * 16 + (g & 1) * 8) = pack_bf16x4(v);
       }
-      __builtin_amdgcn_wave_barrier();
+      for (int pc = 0; pc < o.split; ++pc) {
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int row = it * 8 + (lane >> 3), c = lane & 7;
-        const uint4 val = *reinterpret_cast<const uint4*>(patch + row * 128 + ((c ^ (row & 7)) * 16));
-        const int mr = j * 16 + row;
-        if constexpr (SMODE == 1) {
-          asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));
-        } else {
-          if (FULL || mr < o.rows) *reinterpret_cast<uint4*>(o.c + ((uint32_t)mr * o.ldc_b + c * 16)) = val;
+        for (int i = 0; i < 4; ++i) {
+          const int chunk = (i * 2 + (g >> 1)) ^ (r16 & 7);
+          const uint2 pk = pack_bf16x4(v[i]);
+          *reinterpret_cast<uint2*>(patch + r16 * 128 + chunk * 16 + (g & 1) * 8) = pk;
+          v[i] -= unpack_bf16x4(pk);
         }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 8 + (lane >> 3), c = lane & 7;
+          const uint4 val = *reinterpret_cast<const uint4*>(patch + row * 128 + ((c ^ (row & 7)) * 16));
+          const int mr = j * 16 + row;
+          if constexpr (SMODE == 1) {
+            asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));
+          } else {
+            if (FULL || mr < o.rows) *reinterpret_cast<uint4*>(o.c + pc * o.c_ps_b + ((uint32_t)mr * o.ldc_b + c * 16)) = val;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
     } else {
       // 16 rows x 64 cols fp32: patch[16][256 B], chunk c (16 B) at c ^ row
 #pragma unroll
@@ -779,7 +789,12 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
           *pc = val;
           if constexpr (EPI == GRAM_EPI_F32_ADD) {
             if (o.xb) {
-              *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + c * 8)) = pack_bf16x4(val);
+              f32x4 rem = val;
+              for (int pc = 0; pc < o.split; ++pc) {
+                const uint2 pk = pack_bf16x4(rem);
+                *reinterpret_cast<uint2*>(o.xb + pc * o.xb_ps_b + ((uint32_t)mr * o.ldx_b + c * 8)) = pk;
+                rem -= unpack_bf16x4(pk);
+              }
               ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
             }
           }
@@ -814,7 +829,7 @@ __device__ __forceinline__ void pp_store_rows(f32x4 (&acc)[4][8], int j0, char* 
 
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                         int K, int lda, EpiArgs ep, int ntiles, int stagger) {
+                                                         int K, int lda, EpiArgs ep, int ntiles, int stagger, KSplit ks) {
   constexpr int TB = 256, HT = 16384;
   constexpr bool F32OUT = EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD;
   constexpr bool KV = EPI == PP_KV_K || EPI == PP_KV_V;  // n-tiles of the K blocks only / of the V blocks only
@@ -825,7 +840,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // TEND: the epilogue runs at the end of the tile, both wave groups in step (fp32 outputs).  ABL 7 = the same for bf16
   // outputs (microbench variant 27): 1 035 vs 1 105 TFLOP/s for the in-slot jobs on the encoder QKV shape, so bf16 stays in-slot
   constexpr bool LSE = EPI == GRAM_EPI_F32_LSE;  // lm_head in sparse mode: only the (max, sum exp) partials leave the kernel
-  constexpr bool TEND = (EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD) || LSE || (ABL == 7 && (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU));
+  // ABL 7 also serves the split-bf16 modes: their bf16 / bank outputs are several pieces per value (a store count the in-slot
+  // jobs' counted waits do not cover), and with a 3x / 6x longer k-loop the tile-end placement costs little
+  constexpr bool TEND = (EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD) || LSE || ABL == 7;
+  constexpr bool SPLIT = ABL == 7;  // every split-operand GEMM runs on an ABL 7 instantiation: the plain kernels carry none of its state
   constexpr int RS_OFF = 8 * HT + 4 * 4096;  // bf16 epilogues: 2 x 1 KiB of row scales behind the patches
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 8 half-tile buffers + epilogue patches (+ row scales)
   const int tid = threadIdx.x;
@@ -873,6 +891,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // DMA cursor = stream k-tile kk+2 (tile, kt) + per-lane byte offsets of this wave's 2 pieces of each half-tile type
   // (relative to the tile's first A row / W row, whose addresses c_A / c_W are wave-uniform and 64-bit)
   int c_tile = slot, c_kt = 0;
+  // split-bf16 operands (KSplit): k-tile c_kin of chunk c_chunk; the chunk's A piece starts c_aoff bytes after piece 0
+  int c_kin = 0, c_chunk = 0;
+  long c_aoff = SPLIT ? ks_acol(ks, 0) * 2 : 0;
   // W offsets never change (H2 = H1 + 32 rows goes into the uniform base); A offsets change only for the M-tail tile
   const char *c_A, *c_W;
   uint32_t offA[2][2], offW[2], offW2[LSE ? 2 : 1];  // LSE: W rows clamped per tile (the last n-tile may be half empty)
@@ -908,8 +929,19 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     }
   };
   auto advance = [&]() {
+    if constexpr (SPLIT) {
+      if (++c_kin == ks.nktc) {
+        c_kin = 0;
+        ++c_chunk;
+        c_aoff = ks_acol(ks, c_chunk) * 2;
+      }
+    }
     if (++c_kt == nkt) {
       c_kt = 0;
+      if constexpr (SPLIT) {
+        c_chunk = 0;
+        c_aoff = ks_acol(ks, 0) * 2;
+      }
       if (c_tile + G < ntiles) c_tile += G;  // past the end of the stream: fetch this tile again (harmless, keeps the counts uniform)
       set_offsets();
     }
@@ -918,7 +950,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     if constexpr (ABL != 2) {
       const uint32_t dst = wave_lds + (par * 4 + t) * HT;
       if (t == 0 || t == 3) {
-        const char* base = c_A + c_kt * (BK * 2);
+        const char* base = SPLIT ? c_A + c_aoff + c_kin * (BK * 2) : c_A + c_kt * (BK * 2);
         dma16_asm(dst, offA[t == 3][0], base);
         dma16_asm(dst + 1024, offA[t == 3][1], base);
       } else {
@@ -1163,6 +1195,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     o.c = q.kb - (size_t)J0 * 16 * 128;
     o.ldc_b = 128;
     o.rows = M - (tm0 + wr * 128);
+    o.split = 1;
     return o;
   };
   // extra = number of epilogue stores this wave has issued since the DMA that must have landed (a lower bound is
@@ -1227,6 +1260,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     o.ldx_b = ep.ldc * 2;
     o.ss_nblk = ep.ss_out_nblk;
     o.rows = M - (int)mf;
+    o.split = ep.split;
+    o.c_ps_b = ep.c_pstride * 2;
+    o.xb_ps_b = ep.xb_pstride * 2;
     return o;
   };
   // one MFMA slot of quadrant (mq, nq), optionally with the epilogue job "store m-tiles J0, J0+1 of tile (tm0, tn0)"
@@ -1268,8 +1304,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       const bool first = kt == 0, last = kt + 2 >= nkt;
       // bf16 epilogues of FULL tiles issue exactly 4 stores per store slot (the slots p2, p3 of a tile's last k-tile
       // and p0, p1 of the next tile's first): pf / lf = such stores were / are issued around this k-tile pair
-      const bool pf = !F32OUT && !KV && STORES && first && pending && M - (pm0 + wr * 128) >= 128;
-      const bool lf = !F32OUT && !KV && STORES && last && M - (m0 + wr * 128) >= 128;
+      const bool pf = !TEND && !F32OUT && !KV && STORES && first && pending && M - (pm0 + wr * 128) >= 128;
+      const bool lf = !TEND && !F32OUT && !KV && STORES && last && M - (m0 + wr * 128) >= 128;
       // ================= even k-tile (buffers 0): n order 0, 1
       // Epilogue of the previous tile's m1 half (m-tiles 4..7, finished by its last MFMA slot): fp32 outputs store it
       // in the load slots of p0 / p1, bf16 outputs inside the MFMA slots of p0 / p1 (which compute m0 quadrants).
@@ -1352,6 +1388,27 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
             if (g == 0 && m < M) *reinterpret_cast<float2*>(ep.lse_part + ((size_t)m * ep.lse_nblk + blk) * 2) = make_float2(mx, sm);
           }
         }
+      } else if constexpr (KV) {
+        // bank pieces straight from the accumulators (8 B per lane and piece): K rows / V^T columns of this wave's head
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // opaque: the addresses below are built here, not hoisted into the k-loop's registers
+        const int lr = ln & 15, lg = ln >> 4;
+#pragma unroll
+        for (int J0 = 0; J0 < 8; J0 += 2) {
+          if (m0 + wr * 128 + J0 * 16 < M) {
+            KVLoc q = kv_locate(m0, n0, J0);
+            for (int pc = 0; pc < ep.split; ++pc) {
+#pragma unroll
+              for (int pcs = 0; pcs < 8; ++pcs) {
+                f32x4& v = acc[pcs & 3][J0 + (pcs >> 2)];
+                kv_direct(std::integral_constant<bool, TRALL>{}, q, pcs >> 2, pcs & 3, v, lr, lg);
+                v -= unpack_bf16x4(pack_bf16x4(v));
+              }
+              q.kb += ep.bank_pstride * 2;
+              q.vb += ep.bank_pstride * 2;
+            }
+          }
+        }
       } else {
       const PPOut o = make_out(m0, n0);
       if constexpr (F32OUT) {
@@ -1412,11 +1469,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
 }
 
 template <int EPI, int ABL = 0>
-int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
   if constexpr (EPI == GRAM_EPI_KV_BANK) {  // the public id: both halves, one launch each (no kernel of its own)
-    const int r = launch_pp<PP_KV_K, ABL>(A, W, M, N, K, lda, ep, st);
-    return r ? r : launch_pp<PP_KV_V, ABL>(A, W, M, N, K, lda, ep, st);
+    const int r = launch_pp<PP_KV_K, ABL>(A, W, M, N, K, lda, ep, ks, st);
+    return r ? r : launch_pp<PP_KV_V, ABL>(A, W, M, N, K, lda, ep, ks, st);
   } else {
+  if (ks.np > 1 && ABL != 7) return GRAM_E_ARG;
   constexpr int smem = 8 * 16384 + 8 * 4096;  // 160 KiB
   if ((EPI == GRAM_EPI_F32_LSE ? N % 128 : N % 256) || (K / BK) % 2 || K / BK < 4 || (ep.ss_in && ep.ss_nblk != 0)) return GRAM_E_ARG;
   if (EPI == GRAM_EPI_F32_LSE && ep.C) return GRAM_E_ARG;  // dense logits: the 128-row kernels
@@ -1453,7 +1511,7 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     const int ntn_ = ntiles / ((M + 255) / 256);
     const int gm = ntn_ >= 8 && gm_env > 1 && gm_env < 256 ? gm_env : 0;
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda,
-                       ep, ntiles, (g_stagger & 0xffff) | (gm << 16));
+                       ep, ntiles, (g_stagger & 0xffff) | (gm << 16), ks);
     GRAM_CHECK_LAUNCH();
     return 0;
   }
@@ -1512,10 +1570,12 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
   // The ping-pong kernel declines shapes it does not cover (GRAM_E_ARG); those run on the 256x128 tiles.
   // GRAM_GEMM_PP=0 (A/B hook) keeps it out altogether.
   static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
-  const bool pp_ok = use_pp && ks.np == 1;
+  const bool pp_ok = use_pp != 0;
+  // split operands: bf16 / bank results leave the ping-pong kernel at the tile end (its ABL 7 instantiation)
+  auto pp = [&]() { return ks.np > 1 ? launch_pp<EPI, 7>(A, W, M, N, K, lda, ep, ks, st) : launch_pp<EPI>(A, W, M, N, K, lda, ep, ks, st); };
   if constexpr (EPI == GRAM_EPI_F32_LSE) {  // 64-column wave tiles only: the ping-pong kernel (partials only) or the 128-row kernels
     if ((g_force_variant == V_PP || (g_force_variant < 0 && pp_ok && M >= 32768)) && !ep.C) {
-      const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
+      const int r = pp();
       if (r != GRAM_E_ARG) return r;
     }
     const int pv = pick_variant(M, N, K);
@@ -1525,7 +1585,7 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
   } else {
   if constexpr (EPI == GRAM_EPI_F32_ADD) {  // big-M residual GEMMs: the ping-pong kernel with its tile-end epilogue, whatever N and K
     if (g_force_variant < 0 && pp_ok && M >= 32768) {
-      const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
+      const int r = pp();
       if (r != GRAM_E_ARG) return r;
     }
   }
@@ -1534,7 +1594,7 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
     case V_DMA_M64: return launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, ks, st);
     case V_PP:
       if (g_force_variant == V_PP || pp_ok) {
-        const int r = launch_pp<EPI>(A, W, M, N, K, lda, ep, st);
+        const int r = pp();
         if (r != GRAM_E_ARG || g_force_variant == V_PP) return r;
       }
       [[fallthrough]];

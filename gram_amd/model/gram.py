@@ -470,12 +470,14 @@ class GRAM(nn.Module):
         c_map = torch.cat([midx, hidx]).to(torch.int32).contiguous()
         keep = [c_ids, c_mask, c_map]
         comp = _lib.Compaction(n_miss + n_hit, c_map.data_ptr(), c_ids.data_ptr(), c_mask.data_ptr(), 0, 0, None, None)
+        tens = dict(comp_map=c_map, comp_ids=c_ids, comp_mask=c_mask, cache_slot=None, cache_x=None, n_cached=0, cache_L=0)
         if n_hit:
             slots = slot.index_select(0, hidx).to(torch.int32).contiguous()
             keep += [slots, self._pcache["x"]]
             comp.n_cached, comp.cache_L = n_hit, self._CACHE_L
             comp.cache_x, comp.cache_slot = self._pcache["x"].data_ptr(), slots.data_ptr()
-        return comp, keep
+            tens.update(cache_slot=slots, cache_x=self._pcache["x"], n_cached=n_hit, cache_L=self._CACHE_L)
+        return comp, keep, tens
 
     # ------------------------------------------------------------------ the hot path
     @torch.no_grad()
@@ -523,22 +525,19 @@ class GRAM(nn.Module):
                                                 prefix_allowed_tokens_fn, return_dict_in_generate)
         comp = self._plan_encoder(ids, mask, B, N, Lp)
         flat = self._flat_trie(prefix_allowed_tokens_fn)
-        ctrie, _keep = flat.to_device(dev)
+        _ctrie, (t_off, t_tok, t_node) = flat.to_device(dev)
         ws = self._get_workspace(handle, B, N, Lp, K, int(max_length))
         if K == 1 and nret != 1:
             raise ValueError("num_return_sequences must be 1 for greedy search (num_beams == 1), as in HF generate")
-        seqs = torch.empty(B * nret, int(max_length), dtype=torch.int64, device=dev)
-        # num_beams == 1 is HF's greedy_search: it has no sequences_scores
-        scores = torch.empty(B * nret, dtype=torch.float32, device=dev) if K > 1 else None
-        width = C.c_int32(0)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
-            rc = lib.gram_generate_ex(handle, ids.data_ptr(), mask.data_ptr(), B, N, Lp, K, nret, int(max_length),
-                                      float(length_penalty), C.byref(ctrie), C.byref(comp[0]) if comp else None, ws.data_ptr(),
-                                      ws.numel(), seqs.data_ptr(), scores.data_ptr() if scores is not None else None,
-                                      C.byref(width), stream)
-        _lib.check(rc, "gram_generate")
-        seqs = seqs[:, : width.value]
+        ct = comp[2] if comp else dict(comp_map=None, comp_ids=None, comp_mask=None, cache_slot=None, cache_x=None, n_cached=0, cache_L=0)
+        # the whole path is ONE PyTorch-ROCm custom op over the C ABI (gram_amd/ops.py -> gram_generate_ex)
+        from .. import ops as _ops  # noqa: F401  (registers torch.ops.gram.*)
+        seqs, scores, width = torch.ops.gram.generate(
+            ids, mask, int(handle), ws, t_off, t_tok, t_node, int(flat.max_fanout), int(flat.min_seq_len), K, nret, int(max_length),
+            float(length_penalty), ct["comp_map"], ct["comp_ids"], ct["comp_mask"], ct["cache_slot"], ct["cache_x"],
+            int(ct["n_cached"]), int(ct["cache_L"]))
+        seqs = seqs[:, : int(width[0])]
+        scores = scores if K > 1 else None  # num_beams == 1 is HF's greedy_search: it has no sequences_scores
         if not return_dict_in_generate:
             return seqs
         return GenerateOutput(sequences=seqs, sequences_scores=scores)

@@ -261,3 +261,88 @@ def test_split_generate_vs_oracle(G, mode, tol, name, B, N, L, K):
         gaps = (rs.view(B, K)[:, :-1] - rs.view(B, K)[:, 1:]).abs()
         assert float(gaps.min()) < tol, "sequences differ although no two oracle scores are within the tolerance"
         assert float((rs.sort().values - ds.sort().values).abs().max()) < tol
+
+
+@pytest.mark.parametrize("pieces", [2, 3])
+@pytest.mark.parametrize("M,N,K", [(256 * 40 + 100, 768, 256), (520, 512, 512), (256 * 9, 2304, 768)])
+def test_split_gemm_persistent_matches_tiles(G, pieces, M, N, K):
+    """The persistent ping-pong kernel on split operands (tile-end epilogues, A pieces walked chunk by chunk) against the
+    256x128-tile kernel: same MFMA sequence per accumulator, so every output -- bf16 pieces, fp32, residual + its pieces +
+    sums of squares, LSE partials, the bank -- is compared bit for bit; several tiles per workgroup and an M tail."""
+    from gram_amd import _lib
+    L_ = G.lib()
+    a32, w32 = _r(M, K, seed=11).to(G.DEV), _r(N, K, seed=12, scale=K ** -0.5).to(G.DEV)
+    A, W = pieces_of(a32, pieces), expand_w(w32, pieces)
+    sp = _lib.Split(pieces, M * K, M * N, M * N, 0)
+    rs = (torch.rand(M, generator=torch.Generator().manual_seed(13)) + 0.5).to(G.DEV)
+    base = _r(M, N, seed=14).to(G.DEV)
+    outs = {}
+    try:
+        for v in (3, 22):
+            L_.gram_debug_set_gemm_variant(v)
+            o = {}
+            for epi in (_lib.EPI_BF16, _lib.EPI_BF16_RELU):
+                y = torch.zeros(pieces, M, N, dtype=torch.bfloat16, device=G.DEV)
+                cons = _lib.NormFusion(None, None, rs.data_ptr(), 0, K, 1e-6)
+                _lib.check(L_.gram_gemm_bf16_split(G.p(A), G.p(W), G.p(y), M, N, K, K, N, epi, None, C.byref(cons), C.byref(sp), G.stream()), "bf16")
+                o[("bf16", epi)] = y
+            f = torch.zeros(M, N, dtype=torch.float32, device=G.DEV)
+            _lib.check(L_.gram_gemm_bf16_split(G.p(A), G.p(W), G.p(f), M, N, K, K, N, _lib.EPI_F32, None, None, C.byref(sp), G.stream()), "f32")
+            o["f32"] = f
+            x = base.clone()
+            xb = torch.zeros(pieces, M, N, dtype=torch.bfloat16, device=G.DEV)
+            ss = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=G.DEV)
+            prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
+            _lib.check(L_.gram_gemm_bf16_split(G.p(A), G.p(W), G.p(x), M, N, K, K, N, _lib.EPI_F32_ADD, None, C.byref(prod), C.byref(sp), G.stream()), "add")
+            o["add"], o["xb"], o["ss"] = x, xb, ss
+            part = torch.full((M, N // 64, 2), float("nan"), dtype=torch.float32, device=G.DEV)
+            _lib.check(L_.gram_gemm_bf16_lse_split(G.p(A), G.p(W), None, G.p(part), M, N, K, K, N, C.byref(sp), G.stream()), "lse")
+            o["lse"] = part
+            torch.cuda.synchronize()
+            outs[v] = o
+    finally:
+        L_.gram_debug_set_gemm_variant(-1)
+    ref = a32.double() @ w32.double().T
+    assert relerr(outs[22]["f32"], ref) < TOL[pieces]
+    for key in outs[3]:
+        assert torch.equal(outs[3][key], outs[22][key]), key
+
+
+@pytest.mark.parametrize("pieces", [2, 3])
+@pytest.mark.parametrize("compact", [False, True])
+def test_split_gemm_kv_bank_persistent(G, pieces, compact):
+    from gram_amd import _lib
+    L_ = G.lib()
+    layers, H, d, pN, pL = 2, 4, 256, 3, 64
+    inner, S = H * 64, pN * pL
+    if compact:
+        B = 30
+        keep = torch.rand(B * pN, generator=torch.Generator().manual_seed(5)) < 0.85
+        keep[0] = True
+        pmap = torch.nonzero(keep).flatten().to(torch.int32)
+        P = int(pmap.numel())
+        if (P * pL) % 256 == 0:
+            pmap, P = pmap[:-1], P - 1
+        M = P * pL
+    else:
+        B = 33
+        M, pmap = B * S, None
+    a32, w32 = _r(M, d, seed=41).to(G.DEV), _r(layers * 2 * inner, d, seed=42, scale=d ** -0.5).to(G.DEV)
+    A, W = pieces_of(a32, pieces), expand_w(w32, pieces)
+    res = {}
+    try:
+        for v in (3, 22):
+            L_.gram_debug_set_gemm_variant(v)
+            k = torch.zeros(pieces, layers, B, H, S, 64, dtype=torch.bfloat16, device=G.DEV)
+            vt = torch.zeros(pieces, layers, B, H, 64, S, dtype=torch.bfloat16, device=G.DEV)
+            pm = pmap.to(G.DEV) if compact else None
+            bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, B, H, S, pm.data_ptr() if compact else None, pN, pL)
+            sp = _lib.Split(pieces, M * d, 0, 0, k[0].numel())
+            _lib.check(L_.gram_gemm_bf16_split(G.p(A), G.p(W), None, M, layers * 2 * inner, d, d, 0, _lib.EPI_KV_BANK, C.byref(bank), None,
+                                               C.byref(sp), G.stream()), "kv")
+            torch.cuda.synchronize()
+            res[v] = (k, vt)
+    finally:
+        L_.gram_debug_set_gemm_variant(-1)
+    assert res[22][0].abs().sum() > 0
+    assert torch.equal(res[3][0], res[22][0]) and torch.equal(res[3][1], res[22][1])

@@ -207,3 +207,25 @@ def test_flat_trie_cache_tracks_the_trie_object():
     assert m._flat_trie(fn) is a          # same object: cached
     trie.add([0, 2, 4, 1])
     assert m._flat_trie(fn) is not a      # grown in place: rebuilt
+
+
+def test_dropin_launcher_resolves_bare_names_to_gram_amd(tmp_path):
+    """`python -m gram_amd.dropin script.py`: a script living next to its OWN `model` / `runner` packages (like
+    main_generative_gram.py in src/) gets gram_amd's instead, while its other sibling imports still resolve locally."""
+    import subprocess
+    import sys
+    src = tmp_path / "src"
+    for pkg in ("model", "runner"):
+        (src / pkg).mkdir(parents=True)
+        (src / pkg / "__init__.py").write_text("raise ImportError('the reference package was imported')\n")
+    (src / "arguments.py").write_text("FLAG = 'reference arguments module'\n")
+    (src / "main.py").write_text(
+        "import sys\nfrom runner import get_runner\nfrom model import create_model\nfrom arguments import FLAG\n"
+        "print(get_runner.__module__, create_model.__module__, FLAG, sys.argv[1:])\n"
+        "try:\n    get_runner('nope', *[None] * 8)\nexcept ValueError as e:\n    print('ValueError', e)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "gram_amd.dropin", str(src / "main.py"), "--datasets", "Beauty"], cwd=root,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "gram_amd.runner gram_amd.model reference arguments module ['--datasets', 'Beauty']" in out.stdout
+    assert "ValueError Unknown runner type: nope" in out.stdout

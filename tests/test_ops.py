@@ -1,0 +1,57 @@
+"""The ``gram::`` PyTorch custom ops (gram_amd/ops.py): registered with schemas and meta implementations on any host; their
+kernels exist for the ROCm device only -- a CPU tensor must fail loudly (no CPU path).  -m gpu: values through torch.ops."""
+import pytest
+import torch
+
+import gram_amd  # noqa: F401
+from gram_amd import ops  # noqa: F401
+
+
+def test_ops_are_registered_with_fake_impls():
+    for name in ("generate", "linear", "enc_self_attn", "cross_attn_decode", "trie_step"):
+        assert hasattr(torch.ops.gram, name), name
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        a = torch.empty(20, 768, dtype=torch.bfloat16, device="cuda")
+        w = torch.empty(2304, 768, dtype=torch.bfloat16, device="cuda")
+        assert torch.ops.gram.linear(a, w).shape == (20, 2304)
+        q = torch.empty(40, 768, dtype=torch.bfloat16, device="cuda")
+        kb = torch.empty(2, 12, 384, 64, dtype=torch.bfloat16, device="cuda")
+        vt = torch.empty(2, 12, 64, 384, dtype=torch.bfloat16, device="cuda")
+        mk = torch.empty(2, 384, dtype=torch.uint8, device="cuda")
+        assert torch.ops.gram.cross_attn_decode(q, kb, vt, mk, 20).shape == (40, 768)
+        ids = torch.empty(3, 2, 32, dtype=torch.int64, device="cuda")
+        ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+        t = torch.empty(8, dtype=torch.int32, device="cuda")
+        s, sc, wd = torch.ops.gram.generate(ids, ids.to(torch.uint8), 0, ws, t, t, t, 4, 3, 5, 5, 7, 1.0, None, None, None, None, None, 0, 0)
+        assert s.shape == (15, 7) and sc.shape == (15,) and wd.shape == (1,)
+
+
+def test_no_cpu_kernels():
+    a = torch.zeros(16, 64, dtype=torch.bfloat16)
+    w = torch.zeros(128, 64, dtype=torch.bfloat16)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.gram.linear(a, w)
+
+
+@pytest.mark.gpu
+def test_ops_values_on_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import gram_oracle as O
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(77, 256, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(384, 256, generator=g) / 16).to(torch.bfloat16).cuda()
+    ref = a.float() @ w.float().T
+    assert torch.allclose(torch.ops.gram.linear(a, w).float(), ref, atol=2e-2, rtol=1e-2)
+    assert torch.allclose(torch.ops.gram.linear(a, w, True).float(), ref.clamp(min=0), atol=2e-2, rtol=1e-2)
+    B, H, K, S = 2, 2, 5, 96
+    q = (torch.randn(B * K, H * 64, generator=g) * 0.3).to(torch.bfloat16).cuda()
+    kb = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16).cuda()
+    vt = torch.randn(B, H, 64, S, generator=g).to(torch.bfloat16).cuda()
+    mask = torch.rand(B, S, generator=g) > 0.3
+    out = torch.ops.gram.cross_attn_decode(q, kb, vt, mask.cuda().view(torch.uint8).contiguous(), K)
+    qh = q.float().cpu().view(B, K, H, 64).permute(0, 2, 1, 3)
+    ext = ((1.0 - mask.float()) * O.FMIN)[:, None, None, :]
+    ref = O._attend(qh, kb.float().cpu(), vt.float().cpu().transpose(2, 3), ext).reshape(B * K, H * 64)
+    assert torch.allclose(out.float().cpu(), ref, atol=1e-2, rtol=1e-2)
