@@ -337,7 +337,8 @@ def main():
         try:
             pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1]))) if pmc_files else None
-            if pmc and not item_cache and not args.ragged and pmc.get("batch") == B and args.backbone == "t5-base" and (N, L, K) == (3, 128, 20):
+            if (pmc and not item_cache and not args.ragged and pmc.get("batch") == B and pmc.get("precision", "bf16") == args.precision
+                    and args.backbone == "t5-base" and (N, L, K) == (3, 128, 20)):
                 roof_xa["traffic"] = pmc["cross_attn_kernel"]["hbm_bytes_per_launch"]
                 roof_xa["traffic_source"] = "profiles/" + pmc_files[-1]
                 roof_gemm["traffic"] = pmc["gemm_all"]["hbm_bytes_per_launch_avg"]
@@ -375,7 +376,12 @@ def main():
         one = lambda: model.generate(input_ids=ids_d[:1], attention_mask=mask_d[:1], max_length=max_length, prefix_allowed_tokens_fn=fn,
                                      num_beams=K, num_return_sequences=K, length_penalty=1.0)
         one()
-        extras["batch1_ms_per_generate"] = 1e3 * timed(one, 5)
+        extras["batch1_ms_per_generate"] = 1e3 * timed(one, 10)
+        lib.gram_debug_set_graph(1)
+        for _ in range(3):  # (the second call of a small shape captures its HIP graph, later ones replay it)
+            one()
+        extras["batch1_ms_per_generate_hip_graph_replay"] = 1e3 * timed(one, 10)
+        lib.gram_debug_set_graph(-1)
         # (3) the other precision modes on the same batch (weights re-packed; not the headline arithmetic)
         extras["users_per_s_other_modes"] = {}
         for mode in sorted(PIECES):

@@ -110,6 +110,7 @@ SIGNATURES = {
     "gram_decode_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
     "gram_debug_set_gemm_variant": (C.c_int, [C.c_int]),
     "gram_debug_set_live_rows": (C.c_int, [C.c_int]),
+    "gram_debug_set_graph": (C.c_int, [C.c_int]),
     "gram_debug_stream_read": (C.c_int, [vp, C.c_size_t, vp, vp]),
     "gram_prof_enable": (C.c_int, [C.c_uint32, C.c_int]),
     "gram_prof_reset": (C.c_int, []),
@@ -129,7 +130,9 @@ SIGNATURES = {
     "gram_embed_ex_split": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, vp]),
     "gram_rmsnorm_bf16_split": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, f32, f32, vp, C.c_int, C.c_int, vp, C.c_int, i64, vp]),
     "gram_enc_self_attn_split": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64, vp]),
-    "gram_cross_attn_decode_split": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, i64, i64, i64, vp]),
+    "gram_cross_attn_decode_split": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, i64, i64, i64, vp,
+                                               vp]),
+    "gram_mask_key_bits": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "gram_dec_self_attn_split": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64,
                                            i64, vp]),
     "gram_beam_step_sparse_split": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int,

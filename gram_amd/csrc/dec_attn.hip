@@ -24,6 +24,8 @@
 //     gram_t5.py:320-348); unidirectional relative bias, last query row (:586-593).
 //
 // Both kernels take their bf16 operands as 1..3 pieces (gram_split_t in gram_hip.h).
+#include <stdlib.h>
+
 #include "common.h"
 #include "prof.h"
 
@@ -46,24 +48,21 @@ __device__ __forceinline__ int vsw(int row) { return (0x78 >> (((row >> 2) & 3) 
 
 constexpr int XA_TILE = 4096;  // one K tile or one V^T tile of a 32-key step, per piece
 
-template <int NT, bool LIVE, int S>  // NT = 16-beam tiles; LIVE: live-row step (gram_live_rows_t); S = bf16 pieces
-__global__ __launch_bounds__((S == 3 ? 192 : 256), (S == 1 ? 2 : 1)) void cross_attn_kernel(
+// NT = 16-beam tiles; LIVE: live-row step (gram_live_rows_t); S = bf16 pieces; NW = waves per workgroup (1: a wave owns the whole
+// (user, head) and nothing is merged); R = ring stages per wave
+template <int NT, bool LIVE, int S, int NW, int R>
+__global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     const bf16* __restrict__ q, const bf16* __restrict__ kbank, const bf16* __restrict__ vtbank,
     const uint8_t* __restrict__ mask, bf16* __restrict__ out, int K, int H, int Sk, const int32_t* __restrict__ users,
-    const int32_t* __restrict__ rowpos, long q_pstride, long bank_pstride, long out_pstride) {
+    const int32_t* __restrict__ rowpos, long q_pstride, long bank_pstride, long out_pstride, const uint32_t* __restrict__ key_bits) {
   using T = SplitTab<S>;
-  constexpr int NW = S == 3 ? 3 : 4;              // waves per workgroup (three pieces: 48 KiB of ring per wave)
   constexpr int NB = NT * 16;                     // padded beams
   constexpr int STAGE = S * 2 * XA_TILE;          // per wave and ring slot: S x (K tile | V^T tile)
-  constexpr int RING = 2 * STAGE;
-  constexpr int MERGE = (2 * NW * NB + NW * NB * 64) * 4;
-  constexpr int BODY = NW * RING > MERGE ? NW * RING : MERGE;
+  constexpr int RING = R * STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm_m = reinterpret_cast<float*>(smem);   // [NW][NB]     (the merge buffers alias the rings)
   float* sm_l = sm_m + NW * NB;                   // [NW][NB]
   float* sm_o = sm_l + NW * NB;                   // [NW][NB][64]
-  uint32_t* sm_bits = reinterpret_cast<uint32_t*>(smem + BODY);                     // [128] key-valid bits per 32-key step
-  unsigned long long* sm_valid = reinterpret_cast<unsigned long long*>(sm_bits + 128);  // [2] valid-step bits
 
   // live-row step (users != NULL): workgroup y serves user users[y]; q/out rows are the compact rows rowpos[b*K + beam]
   // (-1 = beam not live: zero query, nothing stored)
@@ -76,21 +75,7 @@ __global__ __launch_bounds__((S == 3 ? 192 : 256), (S == 1 ? 2 : 1)) void cross_
   const char* vt = reinterpret_cast<const char*>(vtbank + ((size_t)b * H + h) * 64 * Sk);
   const uint8_t* mk = mask + (size_t)b * Sk;
 
-  bf16x8 qf[S][NT][2];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int beam = 16 * nt + c;
-    int qrow = beam < K ? b * K + beam : -1;
-    if constexpr (LIVE) {
-      if (qrow >= 0) qrow = rowpos[qrow];
-    }
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc)
-#pragma unroll
-      for (int kd = 0; kd < 2; ++kd)
-        qf[pc][nt][kd] = qrow >= 0 ? ld_global_b128(q + pc * q_pstride + (size_t)qrow * inner + h * 64 + 32 * kd + 8 * g) : zero_bf16x8();
-  }
-
+  bf16x8 qf[S][NT][2];  // query fragments: loaded once the ring is primed (below)
   f32x4 o[4][NT];
   float m[NT], l[NT];
 #pragma unroll
@@ -106,23 +91,30 @@ __global__ __launch_bounds__((S == 3 ? 192 : 256), (S == 1 ? 2 : 1)) void cross_
   // the valid steps are dealt round-robin to the waves.  A user with no valid key at all keeps
   // every step: the reference's softmax over all-finfo.min scores is uniform over all S keys.
   const int nsteps = Sk >> 5;
-  for (int st = tid; st < 128; st += NW * 64) {
-    uint32_t bits = 0;
-    if (st < nsteps) {
-      const uint4* p = reinterpret_cast<const uint4*>(mk + 32 * st);
-      const uint4 a = p[0], c2 = p[1];
-      const uint32_t w8[8] = {a.x, a.y, a.z, a.w, c2.x, c2.y, c2.z, c2.w};
+  // this lane's two words of key bits (steps lane and lane + 64), either precomputed once per generate (gram_mask_key_bits) or
+  // packed here from the mask bytes; every wave holds all of them, so a step's word is one v_readlane away
+  uint32_t kb0 = 0, kb1 = 0;
+  if (key_bits) {
+    if (lane < nsteps) kb0 = key_bits[(size_t)b * 128 + lane];
+    if (lane + 64 < nsteps) kb1 = key_bits[(size_t)b * 128 + 64 + lane];
+  } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+    for (int half = 0; half < 2; ++half) {
+      const int st = lane + 64 * half;
+      uint32_t bits = 0;
+      if (st < nsteps) {
+        const uint4* p = reinterpret_cast<const uint4*>(mk + 32 * st);
+        const uint4 a = p[0], c2 = p[1];
+        const uint32_t w8[8] = {a.x, a.y, a.z, a.w, c2.x, c2.y, c2.z, c2.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bits |= ((w8[i] >> (8 * j)) & 0xffu) ? (1u << (4 * i + j)) : 0u;
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bits |= ((w8[i] >> (8 * j)) & 0xffu) ? (1u << (4 * i + j)) : 0u;
+      }
+      if (half == 0) kb0 = bits; else kb1 = bits;
     }
-    sm_bits[st] = bits;
-    const unsigned long long bal = __ballot(bits != 0u);
-    if (lane == 0) sm_valid[st >> 6] = bal;
   }
-  __syncthreads();
-  unsigned long long v0 = sm_valid[0], v1 = sm_valid[1];
+  unsigned long long v0 = __ballot(kb0 != 0u), v1 = __ballot(kb1 != 0u);
   if ((v0 | v1) == 0ull) {
     v0 = nsteps >= 64 ? ~0ull : ((1ull << nsteps) - 1ull);
     v1 = nsteps > 64 ? ((nsteps >= 128 ? ~0ull : ((1ull << (nsteps - 64)) - 1ull))) : 0ull;
@@ -167,7 +159,8 @@ __global__ __launch_bounds__((S == 3 ? 192 : 256), (S == 1 ? 2 : 1)) void cross_
   const int krow = 8 * (c >> 2) + (c & 3);  // + 4t: key row of S^T tile t this lane feeds
   auto compute = [&](int slot, int step) {
     const char* stg = smem + wave * RING + slot * STAGE;
-    const uint32_t kbits = sm_bits[step] >> (8 * g);  // this lane's keys 8g + 4t + j
+    const uint32_t kword = step < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)kb0, step) : (uint32_t)__builtin_amdgcn_readlane((int)kb1, step - 64);
+    const uint32_t kbits = kword >> (8 * g);  // this lane's keys 8g + 4t + j
     bf16x8 kf[S][2][2], vf[S][4];
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) {
@@ -239,31 +232,98 @@ __global__ __launch_bounds__((S == 3 ? 192 : 256), (S == 1 ? 2 : 1)) void cross_
         for (int pr = 0; pr < T::NP; ++pr) o[mt][nt] = mfma16(vf[T::A[pr]][mt], pf[T::B[pr]][nt], o[mt][nt]);
   };
 
-  // The query loads above are ordinary (compiler-counted) loads; retire them before the first DMA so that every later
-  // vmcnt in this wave counts DMA instructions only.
+  // Everything the first DMAs depend on (the key bits) is in; ordinary loads are retired so that the counted waits below see
+  // DMA instructions only.  The query fragments are loaded AFTER the ring is primed: their latency hides behind the first stages
+  // (hipcc waits for them with vmcnt(0) at their first use, which the first stage has to reach anyway).
   wait_vm<0>();
-  int cur = next(-1);
-  if (cur < nsteps) {
-    int slot = 0;
-    issue(0, cur);
-    int nxt = next(cur);
-    if (nxt < nsteps) issue(1, nxt);
-    while (true) {
-      if (nxt < nsteps) wait_vm<8 * S>();  // all but the newer stage's DMAs have landed: stage `cur` is complete
-      else wait_vm<0>();
-      compute(slot, cur);
-      if (nxt >= nsteps) break;
-      const int nn = next(nxt);
-      if (nn < nsteps) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this slot's fragment reads are done before it is re-filled
-        issue(slot, nn);
+  {
+    // ring of R stages: rq[i] = step held by slot i; `head` is the oldest.  All scalar state.
+    int rq[R];
+    int head = 0, inflight = 0, last = -1;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      rq[i] = nsteps;
+      if (last < nsteps) {
+        last = next(last);
+        if (last < nsteps) {
+          rq[i] = last;
+          issue(i, last);
+          ++inflight;
+        }
       }
-      cur = nxt;
-      nxt = nn;
-      slot ^= 1;
+    }
+    // (query loads)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int beam = 16 * nt + c;
+      int qrow = beam < K ? b * K + beam : -1;
+      if constexpr (LIVE) {
+        if (qrow >= 0) qrow = rowpos[qrow];
+      }
+  #pragma unroll
+      for (int pc = 0; pc < S; ++pc)
+  #pragma unroll
+        for (int kd = 0; kd < 2; ++kd)
+          qf[pc][nt][kd] = qrow >= 0 ? ld_global_b128(q + pc * q_pstride + (size_t)qrow * inner + h * 64 + 32 * kd + 8 * g) : zero_bf16x8();
+    }
+
+    while (inflight > 0) {
+      // all but the (inflight - 1) newer stages' DMAs have landed: the head stage is complete
+      switch (inflight - 1) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<8 * S>(); break;
+        case 2: wait_vm<(R > 2 ? 16 * S : 0)>(); break;
+        default: wait_vm<(R > 3 ? 24 * S : 0)>(); break;
+      }
+      int cur = rq[0];
+#pragma unroll
+      for (int i = 1; i < R; ++i) cur = head == i ? rq[i] : cur;
+      compute(head, cur);
+      --inflight;
+      if (last < nsteps) last = next(last);
+      if (last < nsteps) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this slot's fragment reads are done before it is re-filled
+        issue(head, last);
+#pragma unroll
+        for (int i = 0; i < R; ++i) rq[i] = head == i ? last : rq[i];
+        ++inflight;
+      }
+      head = head + 1 == R ? 0 : head + 1;
     }
   }
 
+  if constexpr (NW == 1) {
+    // one wave owns the whole (user, head): its accumulators are the result (lane: beam 16 nt + c, dims 16 mt + 4 g ..+3)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float lt = l[nt];
+      lt += __shfl_xor(lt, 16, 64);
+      lt += __shfl_xor(lt, 32, 64);
+      const float inv = 1.f / lt;
+      const int beam = 16 * nt + c;
+      int orow = beam < K ? b * K + beam : -1;
+      if constexpr (LIVE) {
+        if (orow >= 0) orow = rowpos[orow];
+      }
+      if (orow >= 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          f32x4 v = o[mt][nt] * inv;
+#pragma unroll
+          for (int pc = 0; pc < S; ++pc) {
+            bf16x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              r[e] = (bf16)v[e];
+              v[e] -= (float)r[e];
+            }
+            *reinterpret_cast<bf16x4*>(out + pc * out_pstride + (size_t)orow * inner + h * 64 + 16 * mt + 4 * g) = r;
+          }
+        }
+      }
+    }
+    return;
+  }
   // merge the waves' partials (the rings are dead once every wave is past its loop)
   __syncthreads();
 #pragma unroll
@@ -313,41 +373,105 @@ __global__ __launch_bounds__((S == 3 ? 192 : 256), (S == 1 ? 2 : 1)) void cross_
   }
 }
 
-template <int NT, int S>
+template <int NT, int S, int NW, int R>
 int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int Sk,
-                 const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, long out_ps, hipStream_t st) {
-  constexpr int NW = S == 3 ? 3 : 4, NB = NT * 16;
-  constexpr int ring = NW * 2 * S * 2 * XA_TILE, merge = (2 * NW * NB + NW * NB * 64) * 4;
-  constexpr int smem = (ring > merge ? ring : merge) + 128 * 4 + 16;
+                 const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, long out_ps, const uint32_t* key_bits, hipStream_t st) {
+  constexpr int NB = NT * 16;
+  constexpr int ring = NW * R * S * 2 * XA_TILE, merge = NW == 1 ? 0 : (2 * NW * NB + NW * NB * 64) * 4;
+  constexpr int smem = ring > merge ? ring : merge;
+  static_assert(smem <= 160 * 1024, "ring does not fit the LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_kernel<NT, false, S>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_kernel<NT, false, S, NW, R>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_kernel<NT, true, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              smem);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attn_kernel<NT, true, S, NW, R>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   if (users)
-    hipLaunchKernelGGL((cross_attn_kernel<NT, true, S>), dim3(H, B), dim3(NW * 64), smem, st, (const bf16*)q, (const bf16*)k,
-                       (const bf16*)vt, mask, (bf16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps);
+    hipLaunchKernelGGL((cross_attn_kernel<NT, true, S, NW, R>), dim3(H, B), dim3(NW * 64), smem, st, (const bf16*)q, (const bf16*)k,
+                       (const bf16*)vt, mask, (bf16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits);
   else
-    hipLaunchKernelGGL((cross_attn_kernel<NT, false, S>), dim3(H, B), dim3(NW * 64), smem, st, (const bf16*)q, (const bf16*)k,
-                       (const bf16*)vt, mask, (bf16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps);
+    hipLaunchKernelGGL((cross_attn_kernel<NT, false, S, NW, R>), dim3(H, B), dim3(NW * 64), smem, st, (const bf16*)q, (const bf16*)k,
+                       (const bf16*)vt, mask, (bf16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
 
+// Waves per workgroup and ring depth per piece count (measured, profiles/r02_cross_attn_variants.json); GRAM_XA_VARIANT = 10*NW + R
+// selects one of the other instantiated shapes for an A/B run.
+#ifndef GRAM_XA_AB
+#define GRAM_XA_AB 0
+#endif
+template <int NT, int S>
+int launch_cross_v(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int Sk,
+                   const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, long out_ps, const uint32_t* key_bits, hipStream_t st) {
+#define XA_ARGS q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits, st
+#if GRAM_XA_AB
+  static const int v = getenv("GRAM_XA_VARIANT") ? atoi(getenv("GRAM_XA_VARIANT")) : 0;
+  if constexpr (NT == 2 && S == 1) {
+    switch (v) {
+      case 22: return launch_cross<NT, S, 2, 2>(XA_ARGS);
+      case 23: return launch_cross<NT, S, 2, 3>(XA_ARGS);
+      case 24: return launch_cross<NT, S, 2, 4>(XA_ARGS);
+      case 43: return launch_cross<NT, S, 4, 3>(XA_ARGS);
+      case 11: return launch_cross<NT, S, 1, 1>(XA_ARGS);
+      case 12: return launch_cross<NT, S, 1, 2>(XA_ARGS);
+      case 13: return launch_cross<NT, S, 1, 3>(XA_ARGS);
+      case 14: return launch_cross<NT, S, 1, 4>(XA_ARGS);
+      case 21: return launch_cross<NT, S, 2, 1>(XA_ARGS);
+      default: break;
+    }
+  }
+  if constexpr (NT == 2 && S == 2) {
+    switch (v) {
+      case 42: return launch_cross<NT, S, 4, 2>(XA_ARGS);
+      case 22: return launch_cross<NT, S, 2, 2>(XA_ARGS);
+      case 23: return launch_cross<NT, S, 2, 3>(XA_ARGS);
+      case 11: return launch_cross<NT, S, 1, 1>(XA_ARGS);
+      case 12: return launch_cross<NT, S, 1, 2>(XA_ARGS);
+      case 13: return launch_cross<NT, S, 1, 3>(XA_ARGS);
+      case 14: return launch_cross<NT, S, 1, 4>(XA_ARGS);
+      case 21: return launch_cross<NT, S, 2, 1>(XA_ARGS);
+      default: break;
+    }
+  }
+#endif
+  // two waves per (user, head), ONE stage each: many small workgroups per CU hide the per-workgroup prologue / merge better than
+  // deep rings do (in-run A/B at the bench shape, tests/bench_xattn.py: (NW, R) = (2, 1) 5.29 / 5.43 TB/s for 1 / 2 pieces against
+  // (1, 2) 5.11 / 5.21, (2, 2) 5.21 / 4.84, (4, 2) 4.49 / 3.88 on the same box)
+  return launch_cross<NT, S, 2, 1>(XA_ARGS);
+#undef XA_ARGS
+}
+
 template <int S>
 int launch_cross_nt(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int Sk,
-                    const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, long out_ps, hipStream_t st) {
+                    const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, long out_ps, const uint32_t* key_bits, hipStream_t st) {
   switch ((K + 15) / 16) {
-    case 1: return launch_cross<1, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, st);
-    case 2: return launch_cross<2, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, st);
-    case 3: return launch_cross<3, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, st);
-    default: return launch_cross<4, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, st);
+    case 1: return launch_cross_v<1, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits, st);
+    case 2: return launch_cross_v<2, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits, st);
+    case 3: return launch_cross_v<3, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits, st);
+    default: return launch_cross_v<4, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits, st);
   }
+}
+
+// key_bits[b][st] bit j = mask[b][32 st + j] != 0 (st < S/32 <= 128; rows are 128 words apart): the cross-attention's view of
+// the mask, the same for every head, layer and decode step of a generate() -- computed once instead of per workgroup
+__global__ __launch_bounds__(128) void mask_key_bits_kernel(const uint8_t* __restrict__ mask, uint32_t* __restrict__ bits, int Sk) {
+  const int b = blockIdx.x, st = threadIdx.x;
+  uint32_t w = 0;
+  if (st < (Sk >> 5)) {
+    const uint4* p = reinterpret_cast<const uint4*>(mask + (size_t)b * Sk + 32 * st);
+    const uint4 a = p[0], c2 = p[1];
+    const uint32_t w8[8] = {a.x, a.y, a.z, a.w, c2.x, c2.y, c2.z, c2.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w |= ((w8[i] >> (8 * j)) & 0xffu) ? (1u << (4 * i + j)) : 0u;
+  }
+  bits[(size_t)b * 128 + st] = w;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,9 +557,17 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restri
 
 }  // namespace
 
+extern "C" int gram_mask_key_bits(const uint8_t* mask, uint32_t* key_bits, int B, int S, void* stream) {
+  if (!mask || !key_bits || B < 1 || S < 32 || (S & 31) || S > 4096 || (reinterpret_cast<uintptr_t>(mask) & 15)) return GRAM_E_ARG;
+  hipLaunchKernelGGL(mask_key_bits_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, mask, key_bits, S);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int gram_cross_attn_decode_split(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
                                             int B, int K, int H, int S, const int32_t* users, const int32_t* rowpos, int pieces,
-                                            int64_t q_pstride, int64_t bank_pstride, int64_t out_pstride, void* stream) {
+                                            int64_t q_pstride, int64_t bank_pstride, int64_t out_pstride, const uint32_t* key_bits,
+                                            void* stream) {
   if (B < 1 || K < 1 || K > GRAM_MAX_BEAMS || H < 1 || S < 32 || (S & 31) || S > 4096 || pieces < 1 || pieces > GRAM_MAX_PIECES ||
       (users == nullptr) != (rowpos == nullptr))
     return GRAM_E_ARG;
@@ -445,22 +577,22 @@ extern "C" int gram_cross_attn_decode_split(const void* q, const void* k_layer, 
   hipStream_t st = (hipStream_t)stream;
   gram_prof::Scope prof(GRAM_K_CROSS_ATTN, st, 4.0 * B * H * S * 64 * pieces);  // K + V^T, bf16, every piece
   switch (pieces) {
-    case 1: return launch_cross_nt<1>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, out_pstride, st);
-    case 2: return launch_cross_nt<2>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, out_pstride, st);
-    default: return launch_cross_nt<3>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, out_pstride, st);
+    case 1: return launch_cross_nt<1>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, out_pstride, key_bits, st);
+    case 2: return launch_cross_nt<2>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, out_pstride, key_bits, st);
+    default: return launch_cross_nt<3>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, out_pstride, key_bits, st);
   }
 }
 
 extern "C" int gram_cross_attn_decode(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
                                       int B, int K, int H, int S, void* stream) {
-  return gram_cross_attn_decode_split(q, k_layer, vt_layer, mask, out, B, K, H, S, nullptr, nullptr, 1, 0, 0, 0, stream);
+  return gram_cross_attn_decode_split(q, k_layer, vt_layer, mask, out, B, K, H, S, nullptr, nullptr, 1, 0, 0, 0, nullptr, stream);
 }
 
 extern "C" int gram_cross_attn_decode_live(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
                                            int n_users, const int32_t* users, const int32_t* rowpos, int K, int H, int S,
                                            void* stream) {
   if (!users || !rowpos) return GRAM_E_ARG;
-  return gram_cross_attn_decode_split(q, k_layer, vt_layer, mask, out, n_users, K, H, S, users, rowpos, 1, 0, 0, 0, stream);
+  return gram_cross_attn_decode_split(q, k_layer, vt_layer, mask, out, n_users, K, H, S, users, rowpos, 1, 0, 0, 0, nullptr, stream);
 }
 
 extern "C" int gram_dec_self_attn_split(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias, void* out,

@@ -1510,8 +1510,12 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     static const int gm_env = getenv("GRAM_GEMM_GROUPM") ? atoi(getenv("GRAM_GEMM_GROUPM")) : 6;  // A/B hook (0/1: n fastest)
     const int ntn_ = ntiles / ((M + 255) / 256);
     const int gm = ntn_ >= 8 && gm_env > 1 && gm_env < 256 ? gm_env : 0;
+    // Tile-end epilogues (ABL 7: the split-operand modes) leave every CU storing at the same moment when all workgroups run in step:
+    // a start stagger spreads the bursts over the tile period (GRAM_GEMM_STAGGER, A/B hook; see gemm_pp_kernel)
+    static const int stagger_env = getenv("GRAM_GEMM_STAGGER") ? atoi(getenv("GRAM_GEMM_STAGGER")) : -1;
+    const int stagger = stagger_env >= 0 ? stagger_env : g_stagger;
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda,
-                       ep, ntiles, (g_stagger & 0xffff) | (gm << 16), ks);
+                       ep, ntiles, (stagger & 0xffff) | (gm << 16), ks);
     GRAM_CHECK_LAUNCH();
     return 0;
   }

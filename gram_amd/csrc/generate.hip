@@ -13,8 +13,23 @@
 #include <vector>
 
 #include "common.h"
+#include "prof.h"
+
+// A captured generate(): the launch train of one problem shape as a HIP graph (small batches are a chain of ~1 000 dependent
+// launches; replaying them from a graph removes the per-launch host cost).  Everything the graph touches lives in the
+// workspace (inputs and results are staged there), so an entry stays valid as long as the workspace and the Trie do.
+struct GraphEntry {
+  int B, N, L, K, nret, Tmax;
+  float lp;
+  const void *ws, *t_off, *t_tok, *t_node;
+  int t_nodes, t_edges, t_fan, t_min;
+  hipGraphExec_t exec;  // nullptr: shape seen once (run eagerly, so that every lazy one-time initialisation has happened)
+};
 
 struct gram_model {
+  std::vector<GraphEntry> graphs;
+  hipStream_t cap_stream = nullptr;  // launches are recorded on a private stream (PyTorch's default stream is the legacy null
+                                     // stream, which cannot capture); the graph is then replayed on the caller's stream
   gram_model_desc_t d;
   std::vector<const float*> enc_ln1, enc_ln2, dec_ln1, dec_ln2, dec_ln3;
   std::vector<const void*> enc_wqkv, enc_wo, enc_wi, enc_wo2, dec_wqkv, dec_wo, dec_wq_x, dec_wo_x, dec_wi, dec_wo2;
@@ -34,6 +49,8 @@ struct Carve {
     return p;
   }
 };
+
+constexpr int64_t kGraphMaxRows = 4096;  // B*K up to which generate() is replayed from a HIP graph (GRAM_GRAPH=0: never)
 
 struct Workspace {
   // encoder
@@ -65,6 +82,12 @@ struct Workspace {
   gram_beam_state_t beam;
   gram_live_rows_t live;
   int32_t* width;
+  uint32_t* key_bits;  // [B][128]  the cross-attention's bit view of the mask (gram_mask_key_bits), once per generate
+  // staging for the graph path: the captured launches read inputs from / write results to the workspace only
+  int64_t* ids_stage;    // [B][N][L]
+  uint8_t* mask_stage;   // [B][N][L]
+  int64_t* seq_stage;    // [B*K][Tmax]
+  float* score_stage;    // [B*K]
   int64_t bytes;
   // split-bf16 modes (gram_split_t): every bf16 buffer above is `pieces` copies, these many elements apart
   int pieces;
@@ -137,6 +160,13 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   w.live.tokens = cv.take<int32_t>(R);
   w.live.counts = cv.take<int32_t>(4);
   w.width = cv.take<int32_t>(4);
+  w.key_bits = cv.take<uint32_t>((int64_t)B * 128);
+  if (R <= kGraphMaxRows) {
+    w.ids_stage = cv.take<int64_t>(Me);
+    w.mask_stage = cv.take<uint8_t>(Me);
+    w.seq_stage = cv.take<int64_t>(R * Tmax);
+    w.score_stage = cv.take<float>(R);
+  }
   w.bytes = (cv.off + 255) & ~(int64_t)255;
   return w;
 }
@@ -213,11 +243,12 @@ struct CachedPassages {  // gram_compaction_t's cache fields
 
 // P passages (all B*N, or the active ones with their flat indices in pmap): the first P - cached.n go through the
 // encoder (ids/mask [P - cached.n][L]), the rest take their residual-stream rows from the passage cache.
-int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const uint8_t* mask, int B, int N, int L, int P,
-           const int32_t* pmap, const CachedPassages& cached, void* st) {
+int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const uint8_t* mask, const uint8_t* full_mask, int B, int N,
+           int L, int P, const int32_t* pmap, const CachedPassages& cached, void* st) {
   const gram_model_desc_t& c = m->d;
   const int d = c.d_model, inner = c.n_heads * 64, H = c.n_heads;
   const int Pe = P - cached.n, Me = P * L;
+  TRY(gram_mask_key_bits(full_mask, w.key_bits, B, N * L, st));
   if (Pe > 0) TRY(encoder_layers(m, w, ids, mask, L, Pe, st));
   if (cached.n > 0) TRY(gram_gather_passage_x(cached.x, cached.slot, w.x + (size_t)Pe * L * d, cached.n, L, cached.cache_L, d, st));
   // final norm + per-passage position embedding = the late fusion (gram.py:238-255); the
@@ -251,7 +282,7 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   auto cross_attn = [&](int i, size_t bank_layer) {
     return gram_cross_attn_decode_split(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd,
                                         live ? live->n_users : B, K, H, S, live ? live->users : nullptr, live ? live->rowpos : nullptr,
-                                        w.pieces, w.ps_qx, w.ps_bank, w.ps_attnd, st);
+                                        w.pieces, w.ps_qx, w.ps_bank, w.ps_attnd, w.key_bits, st);
   };
   const size_t bank_layer = (size_t)B * H * S * 64;
   const size_t cache_layer = (size_t)Tmax * R_cache * inner;
@@ -315,6 +346,11 @@ int search_step(const gram_model* m, const Workspace& w, const gram_trie_t* trie
 
 extern "C" int gram_abi_version(void) { return GRAM_ABI_VERSION; }
 
+static int g_graph = -1;      // -1: the GRAM_GRAPH environment variable decides (default on)
+extern "C" int gram_debug_set_graph(int on) {
+  g_graph = on;
+  return 0;
+}
 static int g_live_rows = -1;  // -1: the GRAM_LIVE_ROWS environment variable decides (default on)
 extern "C" int gram_debug_set_live_rows(int on) {
   g_live_rows = on;
@@ -364,7 +400,13 @@ extern "C" gram_model_t* gram_model_create(const gram_model_desc_t* d) {
   return m;
 }
 
-extern "C" void gram_model_destroy(gram_model_t* m) { delete m; }
+extern "C" void gram_model_destroy(gram_model_t* m) {
+  if (!m) return;
+  for (auto& g : m->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+  delete m;
+}
 
 extern "C" int64_t gram_workspace_bytes(const gram_model_t* m, int B, int N, int L, int K, int max_length) {
   if (check_shapes(m, B, N, L, K, max_length)) return GRAM_E_ARG;
@@ -377,7 +419,7 @@ extern "C" int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids
   TRY(check_shapes(m, B, N, L, K, max_length));
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
-  TRY(encode(m, w, input_ids, mask, B, N, L, B * N, nullptr, CachedPassages{0, 0, nullptr, nullptr}, stream));
+  TRY(encode(m, w, input_ids, mask, mask, B, N, L, B * N, nullptr, CachedPassages{0, 0, nullptr, nullptr}, stream));
   if (enc_out_bf16) {  // (split modes: all the pieces, [pieces][B*N*L][d])
     hipError_t e = hipMemcpyAsync(enc_out_bf16, w.h, (size_t)w.pieces * B * N * L * m->d.d_model * sizeof(bf16), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream);
@@ -415,27 +457,18 @@ extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, co
                           sequences, scores, width_host, stream);
 }
 
-extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K,
-                                int nret, int max_length, float length_penalty, const gram_trie_t* trie,
-                                const gram_compaction_t* comp, void* workspace, int64_t workspace_bytes, int64_t* sequences,
-                                float* scores, int32_t* width_host, void* stream) {
-  TRY(check_shapes(m, B, N, L, K, max_length));
-  if (comp) {
-    const int n_enc = comp->n_active - comp->n_cached;
-    if (comp->n_active < B || comp->n_active > B * N || !comp->passage_map || comp->n_cached < 0 || n_enc < 0) return GRAM_E_ARG;
-    if (n_enc > 0 && (!comp->ids || !comp->mask)) return GRAM_E_ARG;
-    if (comp->n_cached > 0 && (!comp->cache_x || !comp->cache_slot || comp->cache_L < 1)) return GRAM_E_ARG;
-  }
-  if (!trie || nret < 1 || nret > K || !sequences || (!scores && K != 1)) return GRAM_E_ARG;
-  if ((long long)K * trie->max_fanout > 16384) return GRAM_E_ARG;
-  Workspace w = carve(m, workspace, B, N, L, K, max_length);
-  if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
-  w.beam.length_penalty = length_penalty;
+namespace {
+// encode -> search -> finalize of one generate() on `stream`.  capturing: the launches are being recorded into a HIP graph, so
+// nothing here may synchronise (the live-row compaction, whose row counts travel through the host, is left out; results
+// are bit-identical with and without it).
+int generate_body(const gram_model* m, Workspace& w, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K, int nret,
+                  int max_length, const gram_trie_t* trie, const gram_compaction_t* comp, int64_t* sequences, float* scores,
+                  bool capturing, void* stream) {
   if (comp)  // the encoder runs on the active passages only; padded ones leave their bank positions untouched (never read)
-    TRY(encode(m, w, comp->ids, comp->mask, B, N, L, comp->n_active, comp->passage_map,
+    TRY(encode(m, w, comp->ids, comp->mask, mask, B, N, L, comp->n_active, comp->passage_map,
                CachedPassages{comp->n_cached, comp->cache_L, comp->cache_x, comp->cache_slot}, stream));
   else
-    TRY(encode(m, w, input_ids, mask, B, N, L, B * N, nullptr, CachedPassages{0, 0, nullptr, nullptr}, stream));
+    TRY(encode(m, w, input_ids, mask, mask, B, N, L, B * N, nullptr, CachedPassages{0, 0, nullptr, nullptr}, stream));
   TRY(gram_beam_init(&w.beam, trie, /*decoder_start_token_id=*/0, stream));
   if (K == 1) {  // HF: num_beams == 1 -> greedy_search (raw logits, no hypotheses, no scores)
     for (int t = 0; t + 1 < max_length; ++t) {
@@ -448,7 +481,7 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
     const char* e = getenv("GRAM_LIVE_ROWS");
     return !(e && e[0] == '0');
   }();
-  const bool live_rows = g_live_rows < 0 ? live_rows_env : g_live_rows != 0;
+  const bool live_rows = !capturing && (g_live_rows < 0 ? live_rows_env : g_live_rows != 0);  // (the live-row step needs a host round trip)
   // fixed max_length-1 steps: finished users are padded exactly as BeamSearchScorer.process
   // pads them, so skipping HF's all-done early exit changes nothing and needs no host sync
   for (int t = 0; t + 1 < max_length; ++t) {
@@ -484,6 +517,96 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
     TRY(search_step(m, w, trie, t + 1, Kt, nullptr, stream));
   }
   TRY(gram_beam_finalize(&w.beam, nret, max_length, sequences, scores, w.width, stream));
+  }
+  return 0;
+}
+
+// Off unless GRAM_GRAPH=1: measured on MI355X, replaying the ~900 dependent launches of a one-user generate() from a graph
+// takes 20.1 ms against 20.2 ms launched one by one -- the chain is bound by the GPU-side dependency between tiny kernels,
+// not by the host's launch cost (profiles/README.md).
+bool graph_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("GRAM_GRAPH");
+    return e && e[0] == '1';
+  }();
+  return g_graph < 0 ? on : g_graph != 0;
+}
+}  // namespace
+
+extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K,
+                                int nret, int max_length, float length_penalty, const gram_trie_t* trie,
+                                const gram_compaction_t* comp, void* workspace, int64_t workspace_bytes, int64_t* sequences,
+                                float* scores, int32_t* width_host, void* stream) {
+  TRY(check_shapes(m, B, N, L, K, max_length));
+  if (comp) {
+    const int n_enc = comp->n_active - comp->n_cached;
+    if (comp->n_active < B || comp->n_active > B * N || !comp->passage_map || comp->n_cached < 0 || n_enc < 0) return GRAM_E_ARG;
+    if (n_enc > 0 && (!comp->ids || !comp->mask)) return GRAM_E_ARG;
+    if (comp->n_cached > 0 && (!comp->cache_x || !comp->cache_slot || comp->cache_L < 1)) return GRAM_E_ARG;
+  }
+  if (!trie || nret < 1 || nret > K || !sequences || (!scores && K != 1)) return GRAM_E_ARG;
+  if ((long long)K * trie->max_fanout > 16384) return GRAM_E_ARG;
+  Workspace w = carve(m, workspace, B, N, L, K, max_length);
+  if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
+  w.beam.length_penalty = length_penalty;
+  hipStream_t hs = (hipStream_t)stream;
+  // Small batches: replay the launch train from a HIP graph.  Not while per-kernel events are being recorded (bench.py's
+  // profiler), not with a compaction (its arrays are per-call buffers outside the workspace), not for greedy search.
+  const bool graphable = graph_enabled() && !comp && K > 1 && (int64_t)B * K <= kGraphMaxRows && w.ids_stage && gram_prof::g_mask == 0;
+  if (!graphable) {
+    TRY(generate_body(m, w, input_ids, mask, B, N, L, K, nret, max_length, trie, comp, sequences, scores, false, stream));
+  } else {
+    gram_model* mm = const_cast<gram_model*>(m);
+    GraphEntry key{B, N, L, K, nret, max_length, length_penalty, workspace, trie->child_off, trie->child_tok, trie->child_node,
+                   trie->n_nodes, trie->n_edges, trie->max_fanout, trie->min_seq_len, nullptr};
+    GraphEntry* hit = nullptr;
+    for (auto& g : mm->graphs)
+      if (g.B == B && g.N == N && g.L == L && g.K == K && g.nret == nret && g.Tmax == max_length && g.lp == length_penalty &&
+          g.ws == workspace && g.t_off == key.t_off && g.t_tok == key.t_tok && g.t_node == key.t_node && g.t_nodes == key.t_nodes &&
+          g.t_edges == key.t_edges && g.t_fan == key.t_fan && g.t_min == key.t_min)
+        hit = &g;
+    const size_t in_elems = (size_t)B * N * L;
+    hipError_t e = hipMemcpyAsync(w.ids_stage, input_ids, in_elems * sizeof(int64_t), hipMemcpyDeviceToDevice, hs);
+    if (e == hipSuccess) e = hipMemcpyAsync(w.mask_stage, mask, in_elems, hipMemcpyDeviceToDevice, hs);
+    if (e != hipSuccess) return (int)e;
+    if (!hit) {  // first sight of this shape: run it eagerly (on the staged buffers) and remember it
+      if (mm->graphs.size() >= 16) {
+        for (auto& g : mm->graphs)
+          if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        mm->graphs.clear();
+      }
+      mm->graphs.push_back(key);
+      TRY(generate_body(m, w, w.ids_stage, w.mask_stage, B, N, L, K, nret, max_length, trie, nullptr, w.seq_stage, w.score_stage, false,
+                        stream));
+    } else {
+      if (!hit->exec) {  // second call: record the launch train
+        hipGraph_t graph = nullptr;
+        if (!mm->cap_stream) {
+          e = hipStreamCreateWithFlags(&mm->cap_stream, hipStreamNonBlocking);
+          if (e != hipSuccess) return (int)e;
+        }
+        e = hipStreamBeginCapture(mm->cap_stream, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) return (int)e;
+        const int rc = generate_body(m, w, w.ids_stage, w.mask_stage, B, N, L, K, nret, max_length, trie, nullptr, w.seq_stage,
+                                     w.score_stage, true, mm->cap_stream);
+        e = hipStreamEndCapture(mm->cap_stream, &graph);
+        if (rc != 0 || e != hipSuccess || !graph) {
+          if (graph) (void)hipGraphDestroy(graph);
+          return rc != 0 ? rc : (int)e;
+        }
+        e = hipGraphInstantiate(&hit->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+          hit->exec = nullptr;
+          return (int)e;
+        }
+      }
+      e = hipGraphLaunch(hit->exec, hs);
+      if (e != hipSuccess) return (int)e;
+    }
+    e = hipMemcpyAsync(sequences, w.seq_stage, (size_t)B * nret * max_length * sizeof(int64_t), hipMemcpyDeviceToDevice, hs);
+    if (e == hipSuccess && scores) e = hipMemcpyAsync(scores, w.score_stage, (size_t)B * nret * sizeof(float), hipMemcpyDeviceToDevice, hs);
+    if (e != hipSuccess) return (int)e;
   }
   if (width_host) {
     int32_t host[2] = {0, 0};

@@ -129,10 +129,15 @@ int gram_rmsnorm_bf16_split(const float* x, const float* w, void* out_bf16, int 
                             void* stream);
 int gram_enc_self_attn_split(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H,
                              int pieces, int64_t qkv_pstride, int64_t out_pstride, void* stream);
-/* users/rowpos NULL: all B users, rows b*K + beam; else the live-row form (gram_cross_attn_decode_live, B = n_users). */
+/* users/rowpos NULL: all B users, rows b*K + beam; else the live-row form (gram_cross_attn_decode_live, B = n_users).
+ * key_bits: gram_mask_key_bits(mask) computed once per generate (the mask is the same for every head, layer and step), or
+ * NULL: every workgroup packs its user's bits from the mask bytes itself. */
 int gram_cross_attn_decode_split(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out, int B,
                                  int K, int H, int S, const int32_t* users, const int32_t* rowpos, int pieces,
-                                 int64_t q_pstride, int64_t bank_pstride, int64_t out_pstride, void* stream);
+                                 int64_t q_pstride, int64_t bank_pstride, int64_t out_pstride, const uint32_t* key_bits,
+                                 void* stream);
+/* key_bits u32 [B][128]: bit j of word st = mask[b][32*st + j] != 0 (st < S/32). */
+int gram_mask_key_bits(const uint8_t* mask, uint32_t* key_bits, int B, int S, void* stream);
 /* rows NULL: all R rows; else the live-row form (gram_dec_self_attn_live). */
 int gram_dec_self_attn_split(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias, void* out,
                              int R, int n_rows, const int32_t* rows, int H, int t, int Tmax, int pieces, int64_t qkv_pstride,
@@ -427,6 +432,10 @@ int gram_debug_stream_read(const void* src, size_t bytes, void* sink, void* stre
 /* A/B hook (bench.py): 0 = decode every row in every step like the reference, 1 = live-row compaction (gram_live_rows_t),
  * -1 = what the GRAM_LIVE_ROWS environment variable says (default 1).  Results are bit-identical either way. */
 int gram_debug_set_live_rows(int on);
+/* A/B hook: 0 = every generate() launches its kernels one by one, 1 = generate() calls with B*K <= 4 096 rows and no
+ * compaction are replayed from a HIP graph captured on the second call of a shape, -1 = GRAM_GRAPH decides (default 0:
+ * measured without gain on MI355X, see generate.hip). */
+int gram_debug_set_graph(int on);
 
 int gram_abi_version(void);
 

@@ -1,0 +1,58 @@
+"""GPU micro-benchmark (not a test): the cross-attention kernel at the bench shape per (waves per workgroup, ring depth)
+variant.  Needs a library built with -DGRAM_XA_AB=1; each variant runs in its own process (the selector is read once).
+    python tests/bench_xattn.py            # all variants, both piece counts
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def one(pieces, B=4096, H=12, S=384, K=20, reps=20, use_bits=True):
+    import torch
+    from gram_amd import _lib
+    lib = _lib.load()
+    dev = "cuda:0"
+    inner = H * 64
+    q = torch.randn(pieces, B * K, inner, device=dev).to(torch.bfloat16)
+    kb = torch.randn(pieces, B, H, S, 64, device=dev).to(torch.bfloat16)
+    vt = torch.randn(pieces, B, H, 64, S, device=dev).to(torch.bfloat16)
+    mask = torch.ones(B, S, dtype=torch.uint8, device=dev)
+    out = torch.empty(pieces, B * K, inner, dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    bits = torch.zeros(B, 128, dtype=torch.int32, device=dev)
+    _lib.check(lib.gram_mask_key_bits(mask.data_ptr(), bits.data_ptr(), B, S, st), "bits")
+
+    def run():
+        _lib.check(lib.gram_cross_attn_decode_split(q.data_ptr(), kb.data_ptr(), vt.data_ptr(), mask.data_ptr(), out.data_ptr(), B, K, H, S,
+                                                    None, None, pieces, q[0].numel(), kb[0].numel(), out[0].numel(), bits.data_ptr() if use_bits else None, st), "xattn")
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    return us, 4.0 * B * H * S * 64 * pieces / (us * 1e-6) / 1e9
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        for ub in (True, False, True, False):
+            us, gbs = one(int(sys.argv[1]), use_bits=ub)
+            print(json.dumps({"variant": os.environ.get("GRAM_XA_VARIANT", "default"), "pieces": int(sys.argv[1]), "key_bits": ub, "us": round(us, 1), "GBps": round(gbs, 1)}))
+    else:
+        for pieces, variants in ((1, ["", "21", "22", "13"]), (2, ["", "21", "22", "11"])):
+            for v in variants:
+                env = dict(os.environ)
+                if v:
+                    env["GRAM_XA_VARIANT"] = v
+                else:
+                    env.pop("GRAM_XA_VARIANT", None)
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), str(pieces)], env=env, capture_output=True, text=True)
+                print(p.stdout.strip() or p.stderr[-300:], flush=True)

@@ -31,7 +31,7 @@ def _run(cmd, env=None):
 def _check(r, n_gpus, steps):
     assert CONTRACT <= set(r)
     assert r["unit"] == "users/s" and r["n_gpus"] == n_gpus and r["steps"] == steps and r["higher_is_better"] is True
-    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "bf16" and r["data"] == "synthetic"
+    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "bf16x3" and r["data"] == "synthetic"
     assert "workload" in r["config"] and "model" not in r["config"]
     assert abs(r["value"] - n_gpus * 6 * steps / (r["ms_per_step"] * steps / 1e3)) < 1e-6 * r["value"]
     assert r["output_check"]["all_in_trie"] is True
@@ -47,6 +47,16 @@ def test_bench_contract_single_process():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] == "port" and cpu["value"] > 0
     ic = r["config"]["item_cache"]
     assert ic["pool"] == 9 and ic["passages_from_cache_per_step"] > 0 and ic["passages_encoded_per_step"] >= 6
+
+
+def test_bench_spawns_its_own_ranks_and_exchanges_hit_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent starts both ranks before touching the GPU; the timed region ends
+    with the hit-rank all-gather + all-reduce cross-check (gloo here: the two ranks share the one test GPU)."""
+    r = _run([sys.executable, "bench.py", "--gpus", "2", *SMALL, "--cpu-users", "0", "--backend", "gloo", "--share-device"])
+    _check(r, 2, 2)
+    ex = r["exchange"]
+    assert ex["users_gathered"] == 12 and "all_gather_into_tensor" in ex["collective"]
+    assert set(ex["metrics_vs_synthetic_gold"]) == {"hit@5", "hit@10", "ndcg@5", "ndcg@10"}
 
 
 def test_bench_contract_two_ranks_gloo_one_device():

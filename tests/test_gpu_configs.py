@@ -45,6 +45,13 @@ def _realistic_inputs(g, B, N, L, lo=32):
     return ids, mask
 
 
+def _strip(r):
+    r = list(r)
+    while r and r[-1] == 0:
+        r.pop()
+    return tuple(r)
+
+
 def _generate(m, ids, mask, cands, K, lp=1.0):
     from gram_amd.utils import generation_trie as gt
     key = id(cands)
@@ -90,6 +97,40 @@ def test_t5large_beam50_yelp_vs_oracle(gpu):
     out = _generate(m, ids, mask, cands, K)
     assert out["sequences"].shape == ref["sequences"].shape
     _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=0.02)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_config5_full_shape_properties(gpu, precision):
+    """configs[4] at its full shape -- T5-large, N = 21 passages (S = 2 688 fused keys, the long KV the config names),
+    beam 50 (four 16-beam tiles in the cross-attention), the Yelp Trie, T = 11 -- too big for the CPU oracle, so checked
+    through size-independent properties: every hypothesis is a Trie member, none repeats, scores are sorted and finite, a
+    user's result does not depend on the batch it is scored in, and (bf16x3) the scores agree with the plain bf16 run to
+    the bf16 tolerance."""
+    from gram_amd import T5Config
+    gc = T5Config.named("t5-large", max_item_num=20)
+    torch.manual_seed(5)
+    m = gpu.create_model("gram", gc).to(DEV).eval()
+    m.set_precision(precision)
+    cands = _trie_cands("Yelp")
+    cand_set = {tuple(c) for c in cands}
+    g = torch.Generator().manual_seed(55)
+    B, N, L, K = 3, 21, 128, 50
+    ids, mask = _realistic_inputs(g, B, N, L, lo=64)
+    out = _generate(m, ids, mask, cands, K)
+    seqs, scores = out["sequences"].cpu(), out["sequences_scores"].cpu()
+    assert seqs.shape[0] == B * K and torch.isfinite(scores).all()
+    for b in range(B):
+        rows = [_strip(r) for r in seqs[b * K:(b + 1) * K].tolist()]
+        assert all(r in cand_set for r in rows) and len(set(rows)) == K, b
+        s = scores[b * K:(b + 1) * K]
+        assert bool((s[:-1] >= s[1:]).all()), b
+    one = _generate(m, ids[1:2], mask[1:2], cands, K)
+    assert torch.equal(one["sequences_scores"].cpu(), scores[K:2 * K])
+    assert torch.equal(one["sequences"].cpu(), seqs[K:2 * K][:, : one["sequences"].shape[1]])
+    if precision == "bf16x3":
+        m.set_precision("bf16")
+        ref = _generate(m, ids, mask, cands, K)
+        assert float((ref["sequences_scores"].cpu().sort().values - scores.sort().values).abs().max()) < 0.05
 
 
 def test_full_size_properties_and_batch_invariance(gpu):

@@ -158,7 +158,14 @@ def test_split_cross_attn(G, pieces, K, S):
     out = torch.empty(pieces, B * K, inner, dtype=torch.bfloat16, device=G.DEV)
     m8 = mask.to(G.DEV).view(torch.uint8).contiguous()
     _lib.check(G.lib().gram_cross_attn_decode_split(G.p(q), G.p(kb), G.p(vt), G.p(m8), G.p(out), B, K, H, S, None, None, pieces,
-                                                    q[0].numel(), kb[0].numel(), out[0].numel(), G.stream()), "xattn")
+                                                    q[0].numel(), kb[0].numel(), out[0].numel(), None, G.stream()), "xattn")
+    # the same with the mask's bit view precomputed once (what gram_generate does): identical output
+    bits = torch.full((B, 128), -1, dtype=torch.int32, device=G.DEV)
+    _lib.check(G.lib().gram_mask_key_bits(G.p(m8), G.p(bits), B, S, G.stream()), "bits")
+    out2 = torch.empty_like(out)
+    _lib.check(G.lib().gram_cross_attn_decode_split(G.p(q), G.p(kb), G.p(vt), G.p(m8), G.p(out2), B, K, H, S, None, None, pieces,
+                                                    q[0].numel(), kb[0].numel(), out[0].numel(), G.p(bits), G.stream()), "xattn")
+    assert torch.equal(out, out2)
     qh = q32.double().cpu().view(B, K, H, 64).permute(0, 2, 1, 3)
     ext = ((1.0 - mask.float()) * O.FMIN)[:, None, None, :].double()
     sc = torch.matmul(qh, k32.double().cpu().transpose(3, 2)) + ext

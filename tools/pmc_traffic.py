@@ -2,7 +2,7 @@
 """HBM bytes per launch from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) of bench.py
 (tools/profile_round.sh).  gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE tallies 128-B requests at
 64 B, so bytes = FETCH_SIZE[KiB] * 1024 * 2 + WRITE_SIZE[KiB] * 1024.
-    python tools/pmc_traffic.py gpurun_out/pmc_<tag>_fetch gpurun_out/pmc_<tag>_write <batch> > profiles/<tag>_pmc_traffic.json"""
+    python tools/pmc_traffic.py gpurun_out/pmc_<tag>_fetch gpurun_out/pmc_<tag>_write <batch> [precision] > profiles/<tag>_pmc_traffic.json"""
 import csv
 import glob
 import json
@@ -29,7 +29,7 @@ def main():
     fetch, write, batch = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE"), int(sys.argv[3])
     out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 1 --cpu-users 0 --no-prof",
            "correction": "bytes = FETCH_SIZE[KiB]*1024*2 + WRITE_SIZE[KiB]*1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE tallies 128-B requests at 64 B)",
-           "batch": batch}
+           "batch": batch, "precision": sys.argv[4] if len(sys.argv) > 4 else "bf16x3"}
     for key, name in (("cross_attn_kernel", "hbm_bytes_per_launch"), ("gemm_all", "hbm_bytes_per_launch_avg")):
         f, w = fetch.get(key), write.get(key)
         if f and w:
