@@ -1389,23 +1389,48 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
           }
         }
       } else if constexpr (KV) {
-        // bank pieces straight from the accumulators (8 B per lane and piece): K rows / V^T columns of this wave's head
-        int ln = lane;
-        asm volatile("" : "+v"(ln));  // opaque: the addresses below are built here, not hoisted into the k-loop's registers
-        const int lr = ln & 15, lg = ln >> 4;
+        // bank pieces through this wave's 4-KiB patch (no row scales in this epilogue: all 32 KiB behind the half-tiles are
+        // patches), so that K leaves as whole 128-B rows and V^T as 64-B d-rows instead of 8-B fragments
+        char* const kvpatch = smem + 8 * HT + wave * 4096;
 #pragma unroll
         for (int J0 = 0; J0 < 8; J0 += 2) {
           if (m0 + wr * 128 + J0 * 16 < M) {
-            KVLoc q = kv_locate(m0, n0, J0);
-            for (int pc = 0; pc < ep.split; ++pc) {
+            const KVLoc q = kv_locate(m0, n0, J0);
+            if constexpr (!TRALL) {
+              PPOut o = kv_out_k(q, m0, J0);
+              o.split = ep.split;
+              o.c_ps_b = ep.bank_pstride * 2;
+              pp_store_rows_impl<GRAM_EPI_BF16, false>(acc, J0, kvpatch, o, lane, nullptr);
+            } else {
+              // V^T block = 64 columns d x 32 bank positions as [64 d][64 B] (see mma_vt): a lane stores 16 B (8 positions)
+              int ln = lane;
+              asm volatile("" : "+v"(ln));
+              const int lr = ln & 15, lg = ln >> 4;
+              const int wsw = (lr >> 2) & 3, rd = ln >> 2, rc = ln & 3;
+              char* const wbase = kvpatch + lr * 64 + (lg & 1) * 8;
+              const char* const gbase = kvpatch + rd * 64 + ((rc ^ ((rd >> 2) & 3)) * 16);
+              const uint32_t voff0 = ((uint32_t)rd * (uint32_t)ep.S + rc * 8) * 2u;
+              char* vb = q.vb;
+              for (int pc = 0; pc < ep.split; ++pc) {
 #pragma unroll
-              for (int pcs = 0; pcs < 8; ++pcs) {
-                f32x4& v = acc[pcs & 3][J0 + (pcs >> 2)];
-                kv_direct(std::integral_constant<bool, TRALL>{}, q, pcs >> 2, pcs & 3, v, lr, lg);
-                v -= unpack_bf16x4(pack_bf16x4(v));
+                for (int pcs = 0; pcs < 8; ++pcs) {
+                  const int jj = pcs >> 2, pi = pcs & 3;
+                  f32x4& v = acc[pi][J0 + jj];
+                  const uint2 pk = pack_bf16x4(v);
+                  *reinterpret_cast<uint2*>(wbase + pi * 1024 + (((jj * 2 + (lg >> 1)) ^ wsw) * 16)) = pk;
+                  v -= unpack_bf16x4(pk);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                  const uint4 val = *reinterpret_cast<const uint4*>(gbase + it * 1024);
+                  __builtin_nontemporal_store(__builtin_bit_cast(u32x4, val),
+                                              reinterpret_cast<u32x4*>(vb + (voff0 + (uint32_t)(it * 16) * (uint32_t)ep.S * 2u)));
+                }
+                __builtin_amdgcn_wave_barrier();
+                vb += ep.bank_pstride * 2;
               }
-              q.kb += ep.bank_pstride * 2;
-              q.vb += ep.bank_pstride * 2;
             }
           }
         }

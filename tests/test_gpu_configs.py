@@ -130,7 +130,11 @@ def test_config5_full_shape_properties(gpu, precision):
     if precision == "bf16x3":
         m.set_precision("bf16")
         ref = _generate(m, ids, mask, cands, K)
-        assert float((ref["sequences_scores"].cpu().sort().values - scores.sort().values).abs().max()) < 0.05
+        rs, rq = ref["sequences_scores"].cpu(), ref["sequences"].cpu()
+        want = {(i // K, _strip(r)): float(v) for i, (r, v) in enumerate(zip(rq.tolist(), rs))}
+        shared = [abs(want[(i // K, _strip(r))] - float(v)) for i, (r, v) in enumerate(zip(seqs.tolist(), scores))
+                  if (i // K, _strip(r)) in want]
+        assert len(shared) > B * K // 2 and max(shared) < 0.03, (len(shared), max(shared))  # same items, bf16-level score differences
 
 
 def test_full_size_properties_and_batch_invariance(gpu):

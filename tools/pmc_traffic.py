@@ -18,10 +18,11 @@ def load(d, counter):
                 continue
             k = r["Kernel_Name"]
             key = "cross_attn_kernel" if "cross_attn_kernel" in k else "gemm_all" if "gemm_" in k else None
-            if key:
-                per.setdefault(key, {})
-                did = r.get("Dispatch_Id") or r.get("Correlation_Id")
-                per[key][did] = per[key].get(did, 0.0) + float(r["Counter_Value"])  # summed over XCDs / SEs
+            did = r.get("Dispatch_Id") or r.get("Correlation_Id")
+            short = k.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").strip()
+            for kk in ([key] if key else []) + (["kernel:" + short] if ("gemm_" in k or "attn" in k) else []):
+                per.setdefault(kk, {})
+                per[kk][did] = per[kk].get(did, 0.0) + float(r["Counter_Value"])  # summed over XCDs / SEs
     return {k: dict(launches=len(v), avg_KiB_raw=sum(v.values()) / max(len(v), 1)) for k, v in per.items()}
 
 
@@ -34,6 +35,12 @@ def main():
         f, w = fetch.get(key), write.get(key)
         if f and w:
             out[key] = {name: f["avg_KiB_raw"] * 1024 * 2 + w["avg_KiB_raw"] * 1024, "raw": {"FETCH_SIZE": f, "WRITE_SIZE": w}}
+    out["per_kernel"] = {}
+    for k in sorted(set(fetch) | set(write)):
+        if k.startswith("kernel:"):
+            f, w = fetch.get(k, {"launches": 0, "avg_KiB_raw": 0.0}), write.get(k, {"launches": 0, "avg_KiB_raw": 0.0})
+            out["per_kernel"][k[7:]] = {"launches": f["launches"] or w["launches"], "fetch_bytes_per_launch": f["avg_KiB_raw"] * 2048,
+                                        "write_bytes_per_launch": w["avg_KiB_raw"] * 1024}
     json.dump(out, sys.stdout, indent=1)
 
 

@@ -3,7 +3,7 @@
 #   bash tools/profile_round.sh r01e
 # writes gpurun_out/<tag>_bench.json, gpurun_out/prof_<tag>/ (kernel-trace stats) and gpurun_out/pmc_<tag>_{fetch,write}/
 # (HBM counters, one rocprofv3 pass each, never combined with a trace domain); tools/pmc_traffic.py turns the
-# counter CSVs into profiles/<tag>_pmc_traffic.json.
+# counter CSVs into profiles/<tag>_pmc_traffic.json (python tools/pmc_traffic.py gpurun_out/pmc_<tag>_fetch gpurun_out/pmc_<tag>_write 4096 bf16x3).
 set -e
 TAG=${1:-round}
 R=$GRAFT_REPO_ROOT
