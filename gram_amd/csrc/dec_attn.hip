@@ -215,14 +215,12 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
           }
         }
       l[nt] = l[nt] * alpha + ps;
-      // Scale the accumulators component by component: one round-1 build of this kernel lowered `o *= alpha` to
-      // v_pk_mul_f32 with alpha broadcast from the register that became the low half of the destination pair and
-      // returned wrong values; scalar multiplies read alpha from its own register every time.
+      // (One round-1 build of this kernel returned wrong values in dims 48-63; the cause was not this scaling -- whose packed
+      // multiply was blamed at the time -- but accumulators read by the loop's back-edge copies 2-7 wait states after their
+      // MFMA, through branches the compiler's hazard padding did not cover: DESIGN.md §4.3.  tools/check_isa_hazards.py
+      // checks every build for that, across the control-flow graph.)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[mt][nt][e] *= alpha;
-      asm volatile("" ::"v"(alpha));  // keeps alpha's register live past the scaling (tools/check_isa_hazards.py scans every build)
+      for (int mt = 0; mt < 4; ++mt) o[mt][nt] *= alpha;
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)

@@ -19,7 +19,7 @@ def load(d, counter):
             k = r["Kernel_Name"]
             key = "cross_attn_kernel" if "cross_attn_kernel" in k else "gemm_all" if "gemm_" in k else None
             did = r.get("Dispatch_Id") or r.get("Correlation_Id")
-            short = k.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").strip()
+            short = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].strip()
             for kk in ([key] if key else []) + (["kernel:" + short] if ("gemm_" in k or "attn" in k) else []):
                 per.setdefault(kk, {})
                 per[kk][did] = per[kk].get(did, 0.0) + float(r["Counter_Value"])  # summed over XCDs / SEs
