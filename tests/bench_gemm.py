@@ -15,7 +15,7 @@ from tests import gpu_util as G  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
-    ap.add_argument("--variants", default="0,1")
+    ap.add_argument("--variants", default="1,3,22", help="0 reg-staged 128x128, 1 LDS-DMA 128x128, 3 256x128, 22 ping-pong 256x256, 30 skinny, 31 64x128")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--stagger", type=int, default=-1)
