@@ -149,6 +149,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own HIP runtime (torch/lib/libamdhip64.so); the library's device pointers and streams come from PyTorch,
+    # so both must talk to ONE runtime instance: load torch's first, then libgram_hip.so's libamdhip64.so.7 dependency resolves
+    # to the copy already in the process.  (Loaded the other way round, generate() fails with hipErrorNoDevice.)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build() or "

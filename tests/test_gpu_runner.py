@@ -105,3 +105,41 @@ def test_distributed_runner_five_ranks_one_gpu_matches_single(tmp_path):
     # same rows in the merged TSV (batch invariance of the kernels: a user's scores do not depend on its batch)
     a, b = open(p_single).read().splitlines(), open(p_dist).read().splitlines()
     assert a[0] == b[0] and sorted(a[1:13]) == sorted(b[1:13])
+
+
+def _rccl_worker(rdzv, ckpt, q):
+    import gram_amd
+    from gram_amd.runner import all_gather_hit_ranks, get_runner
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"file://{rdzv}", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        got = all_gather_hit_ranks(np.array([3, -1, 0, 7], dtype=np.int16), torch.device(DEV))
+        args = fixture_args(eval_batch_size=4, rank=0)
+        model = gram_amd.create_model("gram", _cfg()).to(DEV)
+        runner = get_runner("distributed", model, None, PieceTokenizer(), None, None, None, DEV, args, 0)
+        runner.test(ckpt)
+        q.put((got.tolist(), runner.last_results["total"], runner.last_results["sums"].tolist(), dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_runner_over_rccl_single_rank(tmp_path):
+    """backend="nccl" (= RCCL on ROCm) on the one GPU of the test box: the runner's all-gather / all-reduce run on device tensors
+    through RCCL itself (world size 1 -- more ranks need more GPUs; the 5-rank test above covers the sharding over gloo)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gram_amd
+    from gram_amd.runner import get_runner
+    ckpt = str(tmp_path / "model_rec_best.pt")
+    _checkpoint(ckpt)
+    model = gram_amd.create_model("gram", _cfg()).to(DEV)
+    single = get_runner("single", model, None, PieceTokenizer(), None, None, None, DEV, fixture_args(eval_batch_size=4))
+    single.test(ckpt)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(str(tmp_path / "rdzv"), ckpt, q))
+    p.start()
+    got, total, sums, backend = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0 and backend == "nccl"
+    assert got == [3, -1, 0, 7] and total == 12 and np.allclose(sums, single.last_results["sums"])
