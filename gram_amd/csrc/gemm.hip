@@ -662,6 +662,7 @@ struct PPOut {
   int rows;
   int split;            // bf16 pieces written (gram_split_t); piece p is c_ps_b / xb_ps_b bytes after piece p - 1
   long c_ps_b, xb_ps_b;
+  bool nt;              // streaming (nt) stores for the bf16 rows (A/B hook GRAM_GEMM_NT7)
 };
 template <int EPI, bool FULL, int SMODE = 0>
 __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, char* patch, const PPOut& o, int lane_, const float* rs) {
@@ -702,7 +703,7 @@ __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, c
           if constexpr (SMODE == 1) {
             asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));
           } else {
-            if (FULL || mr < o.rows) *reinterpret_cast<uint4*>(o.c + pc * o.c_ps_b + ((uint32_t)mr * o.ldc_b + c * 16)) = val;
+            if (FULL || mr < o.rows) store16(o.c + pc * o.c_ps_b + ((uint32_t)mr * o.ldc_b + c * 16), val, o.nt);
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1196,6 +1197,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     o.ldc_b = 128;
     o.rows = M - (tm0 + wr * 128);
     o.split = 1;
+    o.nt = true;  // (the bank is next read by another kernel, much later)
     return o;
   };
   // extra = number of epilogue stores this wave has issued since the DMA that must have landed (a lower bound is
@@ -1263,6 +1265,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     o.split = ep.split;
     o.c_ps_b = ep.c_pstride * 2;
     o.xb_ps_b = ep.xb_pstride * 2;
+    o.nt = (ep.nt & 8) != 0;
     return o;
   };
   // one MFMA slot of quadrant (mq, nq), optionally with the epilogue job "store m-tiles J0, J0+1 of tile (tm0, tn0)"
@@ -1537,6 +1540,8 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     const int gm = ntn_ >= 8 && gm_env > 1 && gm_env < 256 ? gm_env : 0;
     // Tile-end epilogues (ABL 7: the split-operand modes) leave every CU storing at the same moment when all workgroups run in step:
     // a start stagger spreads the bursts over the tile period (GRAM_GEMM_STAGGER, A/B hook; see gemm_pp_kernel)
+    static const int nt7 = getenv("GRAM_GEMM_NT7") ? atoi(getenv("GRAM_GEMM_NT7")) : 0;  // A/B hook: streaming stores of the tile-end bf16 rows (measured: no gain)
+    if (nt7) ep.nt |= 8;
     static const int stagger_env = getenv("GRAM_GEMM_STAGGER") ? atoi(getenv("GRAM_GEMM_STAGGER")) : -1;
     const int stagger = stagger_env >= 0 ? stagger_env : g_stagger;
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda,

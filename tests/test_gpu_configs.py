@@ -137,9 +137,12 @@ def test_config5_full_shape_properties(gpu, precision):
         assert len(shared) > B * K // 2 and max(shared) < 0.03, (len(shared), max(shared))  # same items, bf16-level score differences
 
 
-def test_full_size_properties_and_batch_invariance(gpu):
-    """configs[1] at bench scale (B = 96 users, T5-base, Beauty Trie, beam 20): size-independent checks."""
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_full_size_properties_and_batch_invariance(gpu, precision):
+    """configs[1] at bench scale (B = 96 users, T5-base, Beauty Trie, beam 20): size-independent checks, in plain bf16 and in
+    the headline arithmetic (the batches below go through the ping-pong, the 128-row and the skinny GEMM kernels)."""
     oc, sd, m = _model(gpu, "t5-base", 2023)
+    m.set_precision(precision)
     cands = _trie_cands("Beauty")
     cand_set = {tuple(c) for c in cands}
     g = torch.Generator().manual_seed(4)
@@ -200,11 +203,13 @@ def test_batch_invariance_other_backbones(gpu, backbone, B, N, K, dataset):
             assert torch.equal(o2["sequences_scores"][j * K:(j + 1) * K].cpu(), scores[u * K:(u + 1) * K]), u
 
 
-def test_passage_compaction_is_result_neutral(gpu, monkeypatch):
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "bf16x6"])
+def test_passage_compaction_is_result_neutral(gpu, monkeypatch, precision):
     """Ragged batch (users padded to N = 5 with fully masked passages): running the encoder on the active
     passages only gives bit-identical sequences and scores, and the padded bank positions are never read
     (they are poisoned with NaN-pattern garbage first)."""
     oc, sd, m = _model(gpu, "small", 5)
+    m.set_precision(precision)
     cands = _trie_cands("Toys")
     g = torch.Generator().manual_seed(21)
     B, N, L, K = 12, 5, 64, 8  # the 'small' test model has max_item_num = 4
@@ -221,13 +226,14 @@ def test_passage_compaction_is_result_neutral(gpu, monkeypatch):
     assert torch.isfinite(comp["sequences_scores"]).all()
 
 
-@pytest.mark.parametrize("backbone,N,L,K", [("small", 5, 64, 8), ("t5-base", 4, 96, 20)])
-def test_passage_cache_is_result_neutral(gpu, backbone, N, L, K):
+@pytest.mark.parametrize("backbone,N,L,K,precision", [("small", 5, 64, 8, "bf16"), ("t5-base", 4, 96, 20, "bf16"), ("small", 5, 64, 8, "bf16x3")])
+def test_passage_cache_is_result_neutral(gpu, backbone, N, L, K, precision):
     """SURVEY.md §8f N2: item passages drawn from a pool and registered with ``cache_passages`` skip the encoder;
     sequences and scores are bit-identical to encoding everything in place -- with a ragged batch (fully padded
     passages), items at different slots for different users, a cache encoded at L = 128 serving a batch trimmed to
     L < 128, items that are NOT in the cache, and a workspace poisoned with NaN patterns between the runs."""
     oc, sd, m = _model(gpu, backbone, 7)
+    m.set_precision(precision)
     cands = _trie_cands("Toys")
     g = torch.Generator().manual_seed(33)
     B, pool = 10, 7
@@ -351,8 +357,8 @@ def test_live_row_compaction_partial_steps(gpu):
     _check_generate(oc, sd, dict(sequences=seq_live[: 4 * K], sequences_scores=sc_live[: 4 * K]), ref, ids[:4], mask[:4], cands, K, 0.02)
 
 
-@pytest.mark.parametrize("dataset,K", [("Beauty", 20), ("Toys", 8)])
-def test_live_row_compaction_is_result_neutral(gpu, dataset, K):
+@pytest.mark.parametrize("dataset,K,precision", [("Beauty", 20, "bf16"), ("Toys", 8, "bf16"), ("Toys", 8, "bf16x3")])
+def test_live_row_compaction_is_result_neutral(gpu, dataset, K, precision):
     """Last decode step(s) on the live rows only (gram_live_rows_t: beams that left the Trie at EOS are skipped) vs every
     row: bit-identical sequences and scores on the real item Tries (ids of l or l+1 pieces), and the compact step
     really ran (the cross-attention streamed fewer users' banks)."""
@@ -360,6 +366,7 @@ def test_live_row_compaction_is_result_neutral(gpu, dataset, K):
     from gram_amd import _lib
     from gram_amd.utils import generation_trie as gt
     oc, sd, m = _model(gpu, "small", 11)
+    m.set_precision(precision)
     cands = _trie_cands(dataset)
     fn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
     g = torch.Generator().manual_seed(5)
