@@ -131,7 +131,11 @@ class GRAM(nn.Module):
         self._version = 0
         self._workspace = None
         self._tries: Dict[int, tuple] = {}  # id(trie) -> (trie, FlatTrie)
-        self._precision = os.environ.get("GRAM_PRECISION", "bf16")
+        # The reference computes in fp32; "bf16x3" is the cheapest arithmetic that keeps Recall@5 / NDCG@5 within 1e-4 of it
+        # (DESIGN.md §5), so it is what a drop-in model starts in.  GRAM_PRECISION / set_precision() choose another.
+        self._precision = os.environ.get("GRAM_PRECISION", "bf16x3")
+        if self._precision not in self.PRECISIONS:
+            raise ValueError(f"GRAM_PRECISION={self._precision!r}: choose from {self.PRECISIONS}")
         self._pcache = None  # passage cache: dict(x, canon, keys, perm) on the device
 
     # ------------------------------------------------------------------ weights

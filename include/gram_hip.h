@@ -342,7 +342,8 @@ int64_t gram_workspace_bytes(const gram_model_t* m, int B, int N, int L, int K, 
 /* EncoderWrapper.forward + the fused-bank projection (gram.py:200-256; gram_t5_modeling.py
  * T5Stack encoder role; cross K/V projection :531-534 for every decoder layer at once).
  * input_ids i64 [B][N][L], mask u8 [B][N][L].  Writes the bank into the workspace; when
- * enc_out_bf16 != NULL also copies the fused encoder states [B*N*L][d] there (tests). */
+ * enc_out_bf16 != NULL also copies the fused encoder states there (tests): [B*N*L][d] bf16, or in the split modes
+ * their pieces, [pieces][B*N*L][d]. */
 int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N,
                       int L, void* workspace, int64_t workspace_bytes, int K, int max_length,
                       void* enc_out_bf16, void* stream);

@@ -73,13 +73,14 @@ def _encode_device(m, ids, mask, K=2, max_length=6):
     B, N, L = ids.shape
     ws = m._get_workspace(handle, B, N, L, K, max_length)
     d = m.config.d_model
-    enc = torch.empty(B * N * L, d, dtype=torch.bfloat16, device=DEV)
+    pieces = m._PIECES[m._precision]  # split modes: the fused encoder states come back as their bf16 pieces, [pieces][B*N*L][d]
+    enc = torch.empty(pieces, B * N * L, d, dtype=torch.bfloat16, device=DEV)
     idd = ids.to(DEV).contiguous()
     mk = mask.to(DEV).view(torch.uint8).contiguous()
     rc = lib.gram_encode_fused(handle, idd.data_ptr(), mk.data_ptr(), B, N, L, ws.data_ptr(), ws.numel(), K, max_length,
                                enc.data_ptr(), torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "gram_encode_fused")
-    return enc.float().cpu().view(B, N * L, d), ws, mk, handle
+    return enc.float().sum(0).cpu().view(B, N * L, d), ws, mk, handle
 
 
 @pytest.mark.parametrize("name,B,N,L", [("tiny", 2, 3, 32), ("tiny", 3, 2, 64), ("small", 2, 2, 128), ("t5-base", 1, 3, 32)])
