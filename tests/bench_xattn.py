@@ -42,7 +42,11 @@ def one(pieces, B=4096, H=12, S=384, K=20, reps=20, use_bits=True):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
+    if len(sys.argv) > 2:  # pieces B H S K: one shape, e.g. config 5's  `2 512 16 2688 50`
+        pieces, B, H, S, K = (int(x) for x in sys.argv[1:6])
+        us, gbs = one(pieces, B=B, H=H, S=S, K=K)
+        print(json.dumps({"pieces": pieces, "B": B, "H": H, "S": S, "K": K, "us": round(us, 1), "GBps": round(gbs, 1)}))
+    elif len(sys.argv) > 1:
         for ub in (True, False, True, False):
             us, gbs = one(int(sys.argv[1]), use_bits=ub)
             print(json.dumps({"variant": os.environ.get("GRAM_XA_VARIANT", "default"), "pieces": int(sys.argv[1]), "key_bits": ub, "us": round(us, 1), "GBps": round(gbs, 1)}))
