@@ -423,6 +423,16 @@ int launch_cross_v(const void* q, const void* k, const void* vt, const uint8_t* 
       default: break;
     }
   }
+  if constexpr (NT == 4 && S <= 2) {
+    switch (v) {
+      case 11: return launch_cross<NT, S, 1, 1>(XA_ARGS);
+      case 12: return launch_cross<NT, S, 1, 2>(XA_ARGS);
+      case 22: return launch_cross<NT, S, 2, 2>(XA_ARGS);
+      case 41: return launch_cross<NT, S, 4, 1>(XA_ARGS);
+      case 42: return launch_cross<NT, S, 4, 2>(XA_ARGS);
+      default: break;
+    }
+  }
   if constexpr (NT == 2 && S == 2) {
     switch (v) {
       case 42: return launch_cross<NT, S, 4, 2>(XA_ARGS);
@@ -440,7 +450,10 @@ int launch_cross_v(const void* q, const void* k, const void* vt, const uint8_t* 
   // two waves per (user, head), ONE stage each: many small workgroups per CU hide the per-workgroup prologue / merge better than
   // deep rings do (in-run A/B at the bench shape, tests/bench_xattn.py: (NW, R) = (2, 1) 5.29 / 5.43 TB/s for 1 / 2 pieces against
   // (1, 2) 5.11 / 5.21, (2, 2) 5.21 / 4.84, (4, 2) 4.49 / 3.88 on the same box)
-  return launch_cross<NT, S, 2, 1>(XA_ARGS);
+  // (three or four beam tiles, K > 32: the per-workgroup state is larger and one wave per (user, head) with two stages wins --
+  // K = 50, S = 2 688, H = 16: (1, 2) 4.32 / 5.28 TB/s against (2, 1) 3.93 / 4.99, (2, 2) 4.08 / 4.95, (4, 1) 3.66 / 4.75)
+  if constexpr (NT >= 3) return launch_cross<NT, S, 1, 2>(XA_ARGS);
+  else return launch_cross<NT, S, 2, 1>(XA_ARGS);
 #undef XA_ARGS
 }
 
