@@ -7,16 +7,15 @@
 //     shared by all of the user's beams: algorithmic bytes = 2 * S * 64 * 2 B per (user, head)
 //     and bf16 piece of the bank.
 //
-//     Mapping: one workgroup per (user, head), NW waves, wave w owns the valid 32-key steps
-//     w, w+NW, ...  A step's K rows (32 x 128 B) and V^T rows (64 x 64 B) are brought into a
-//     wave-PRIVATE two-stage LDS ring by LDS-DMA (global_load_lds, 16 B per lane, no staging
-//     registers): a wave keeps 16 KiB per bf16 piece in flight whatever its register budget, and
-//     waves never synchronise inside the loop (counted s_waitcnt vmcnt only).  The DMA writes LDS
-//     linearly, so the bank-conflict swizzles are applied to the per-lane SOURCE chunk.
-//     S^T = K Q^T puts a beam on a lane column, so the online softmax is in-register + two
-//     cross-lane steps, and exp(S^T) is directly the B operand of O^T = V^T P^T (same
-//     row-permutation trick as enc_attn.hip).  Waves merge their (m, l, O) partials through LDS
-//     (aliasing the rings) at the end.
+//     Mapping: one workgroup per (user, head), NW waves (template; 2 for K <= 32, 1 above), wave w owns the valid
+//     32-key steps w, w+NW, ...  A step's K rows (32 x 128 B) and V^T rows (64 x 64 B) of every bf16 piece are brought
+//     into a wave-PRIVATE ring of R stages in LDS by LDS-DMA (global_load_lds, 16 B per lane, no staging registers);
+//     waves never synchronise inside the loop (counted s_waitcnt vmcnt only).  The DMA writes LDS linearly, so the
+//     bank-conflict swizzles are applied to the per-lane SOURCE chunk.  S^T = K Q^T puts a beam on a lane column, so
+//     the online softmax is in-register + two cross-lane steps, and exp(S^T) is directly the B operand of
+//     O^T = V^T P^T (same row-permutation trick as enc_attn.hip).  With NW > 1 the waves merge their (m, l, O)
+//     partials through LDS (aliasing the rings) at the end; with NW = 1 the accumulators are the result.
+//     (NW, R) per shape were measured, see launch_cross_v() and DESIGN.md §4.2.
 //
 // (2) dec_self_attn_kernel: causal self-attention of the newest token over <= 32 cached
 //     positions with beam-parent indirection (anc table) instead of the reference's

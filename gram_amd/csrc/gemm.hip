@@ -13,17 +13,19 @@
 // LDS tiles are [128 rows][64 k] bf16 (128-B rows), XOR-swizzled in 16-byte chunks
 // (chunk ^= (row>>1)&7) so the ds_read_b128 lane groups of gfx950 are conflict-free.
 //
-// Staging variants (picked per problem by pick_variant(); measured in tests/bench_gemm.py):
-//   V_REG2  registers -> LDS, 2 LDS stages (64 KiB), loads issued one k-tile ahead, one barrier
-//           per k-tile, 2 workgroups/CU.  Best when the grid cannot fill the chip (decoder at
-//           small batch): the in-block prefetch is the only latency hiding there is.
-//   V_DMA   global_load_lds (LDS-DMA, 16 B/lane, no staging VGPRs), 1 LDS stage (32 KiB),
-//           two barriers per k-tile, 4 workgroups/CU: latency is hidden by the other resident
-//           workgroups (thread-level parallelism) instead of by in-block software pipelining.
-//           The swizzle is applied to the per-lane SOURCE address (the DMA writes LDS linearly).
+// Kernels (picked per problem by pick_variant(); measured in tests/bench_gemm.py):
+//   gemm_pp_kernel     persistent 256x256 "ping-pong" 8-phase kernel (M >= 32 768): see its own header below.
+//   gemm_dma_kernel    global_load_lds (LDS-DMA, 16 B/lane, no staging VGPRs), 1 LDS stage, two barriers per k-tile, up to
+//                      4 workgroups/CU: latency is hidden by the other resident workgroups.  256x128, 128x128 and 64x128
+//                      tiles.  The swizzle is applied to the per-lane SOURCE address (the DMA writes LDS linearly).
+//   gemm_skinny_kernel M <= 64: one 16-column n-tile per wave over the whole K, operands straight from global memory.
+//   gemm_reg2_kernel   registers -> LDS, 2 LDS stages, loads issued one k-tile ahead (the first correct kernel; kept as
+//                      variant 0 for cross-checks).
+// All of them take split-bf16 operands (gram_split_t / KSplit): the k-loop walks nprod chunks of K, chunk c reading A piece
+// GRAM_SPLIT_A_PIECE[c] (a pointer offset) against chunk c of the product-expanded W, and every bf16 result is written as
+// pieces.  The MFMA sequence per accumulator is the same in every kernel, so their outputs are bit-identical.
 // Workgroup ids are remapped XCD-aware (ids i and i+8 share an XCD and its 4 MiB L2): every
-// XCD walks a contiguous range of tiles, n-tile fastest, so an A row-panel is fetched by one
-// XCD only and the (small) weight matrix stays L2-resident.
+// XCD walks a contiguous range of tiles.
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1363,7 +1365,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     const bool more = tile + G < ntiles;
     if constexpr (TEND && STORES) {
       // fp32 outputs: the read-modify-write epilogue runs at the END of the tile with both wave groups in step (like the
-      // other persistent kernel): inside the slots its residual loads drain the in-order DMA queue four times per tile and
+      // 256x128-tile kernel): inside the slots its residual loads drain the in-order DMA queue four times per tile and
       // group; here once.  Group 0 waits for group 1's last MFMA slot, both store, and group 1 falls one barrier behind again.
       if (wr == 0) pp_barrier();
       if constexpr (LSE) {
