@@ -239,39 +239,45 @@ def test_generate_matches_reference_golden(gpu, golden_dir):
 
 
 def test_metric_parity_population(gpu):
-    """Recall@5 / NDCG@5 of device vs oracle over a user population whose gold items sit at known
-    oracle ranks (so the metric is sensitive to every rank flip).  The north-star bound (1e-4) is
-    quoted for a trained model on Beauty; on random weights near-ties are far more frequent, so the
-    bound asserted here is the measured-flip-rate one, and the deltas are printed."""
+    """Recall@5 / NDCG@5 of device vs the CPU oracle over a small user population whose gold items sit at known
+    oracle ranks (so the metric is sensitive to every rank flip), in the model's default arithmetic (bf16x3) and in
+    plain bf16.  The north-star bound itself (1e-4 on 4 096 T5-base users against the fp32 reference) is asserted in
+    tests/test_gpu_precision.py; here: at most a couple of near-tie flips in the default mode, the round-1 bounds in bf16."""
     from gram_amd.utils import evaluate as ev, generation_trie as gt
     oc, sd, m = _model(gpu, "tiny", 11)
-    g = torch.Generator().manual_seed(77)
-    cands = _random_items(g, 300, 3, 4, 40)
-    max_length = max(len(c) for c in cands)
-    K, B, nb = 10, 16, 8
-    ofn = O.prefix_allowed_tokens_fn(O.Trie(cands))
-    dfn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
-    metrics = ["hit@5", "hit@10", "ndcg@5", "ndcg@10"]
-    o_sum, d_sum, total, flips = np.zeros(4), np.zeros(4), 0, 0
-    strip = lambda s: tuple(int(t) for t in s if int(t) not in (0, 1))
-    for it in range(nb):
-        ids, mask = _inputs(g, B, 3, 32, 256)
-        ref = O.generate(sd, oc, ids, mask, max_length, ofn, K, K, 1.0)
-        out = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max_length, prefix_allowed_tokens_fn=dfn,
-                         num_beams=K, num_return_sequences=K)
-        opred = [strip(s) for s in ref["sequences"]]
-        dpred = [strip(s) for s in out["sequences"].cpu()]
-        gold = [opred[b * K + (b + it) % K] for b in range(B)]  # gold = oracle's rank-((b+it)%K) item
-        orel = ev.rel_results(opred, gold, ref["sequences_scores"].tolist(), K)
-        drel = ev.rel_results(dpred, gold, out["sequences_scores"].cpu().tolist(), K)
-        flips += int((ev.hit_ranks(orel) != ev.hit_ranks(drel)).sum())
-        o_sum += ev.get_metrics_results(orel, metrics)
-        d_sum += ev.get_metrics_results(drel, metrics)
-        total += B
-    delta = np.abs(o_sum - d_sum) / total
-    print(f"\n[metric parity] users={total} rank flips={flips} |delta| hit@5/hit@10/ndcg@5/ndcg@10 = {delta}")
-    assert flips <= 0.15 * total
-    assert (delta < 0.05).all(), delta
+    results = {}
+    for mode in ("bf16x3", "bf16"):
+        m.set_precision(mode)
+        g = torch.Generator().manual_seed(77)
+        cands = _random_items(g, 300, 3, 4, 40)
+        max_length = max(len(c) for c in cands)
+        K, B, nb = 10, 16, 8
+        ofn = O.prefix_allowed_tokens_fn(O.Trie(cands))
+        dfn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
+        metrics = ["hit@5", "hit@10", "ndcg@5", "ndcg@10"]
+        o_sum, d_sum, total, flips = np.zeros(4), np.zeros(4), 0, 0
+        strip = lambda s: tuple(int(t) for t in s if int(t) not in (0, 1))
+        for it in range(nb):
+            ids, mask = _inputs(g, B, 3, 32, 256)
+            ref = O.generate(sd, oc, ids, mask, max_length, ofn, K, K, 1.0)
+            out = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max_length, prefix_allowed_tokens_fn=dfn,
+                             num_beams=K, num_return_sequences=K)
+            opred = [strip(s) for s in ref["sequences"]]
+            dpred = [strip(s) for s in out["sequences"].cpu()]
+            gold = [opred[b * K + (b + it) % K] for b in range(B)]  # gold = oracle's rank-((b+it)%K) item
+            orel = ev.rel_results(opred, gold, ref["sequences_scores"].tolist(), K)
+            drel = ev.rel_results(dpred, gold, out["sequences_scores"].cpu().tolist(), K)
+            flips += int((ev.hit_ranks(orel) != ev.hit_ranks(drel)).sum())
+            o_sum += ev.get_metrics_results(orel, metrics)
+            d_sum += ev.get_metrics_results(drel, metrics)
+            total += B
+        delta = np.abs(o_sum - d_sum) / total
+        print(f"\n[metric parity, {mode}] users={total} rank flips={flips} |delta| hit@5/hit@10/ndcg@5/ndcg@10 = {delta}")
+        results[mode] = (flips, delta, total)
+    flips, delta, total = results["bf16x3"]
+    assert flips <= 2 and (delta < 0.02).all(), (flips, delta)
+    flips, delta, total = results["bf16"]
+    assert flips <= 0.15 * total and (delta < 0.05).all(), (flips, delta)
 
 
 def test_greedy_matches_oracle(gpu):
