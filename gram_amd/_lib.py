@@ -18,7 +18,7 @@ GRAM_MAX_PASSAGE_LEN = 128
 EPI_BF16, EPI_BF16_RELU, EPI_F32_ADD, EPI_F32, EPI_KV_BANK = range(5)
 K_GEMM, K_ENC_ATTN, K_CROSS_ATTN, K_DEC_SELF_ATTN, K_ROWOPS, K_LSE, K_BEAM = range(7)
 E_ARG, E_WORKSPACE, E_BEAM = -1, -2, -3
-ABI_VERSION = 3
+ABI_VERSION = 4
 # split-bf16 precision modes (gram_hip.h: GRAM_SPLIT_*): bf16 pieces per value -> products, and the (A piece, W piece) of each
 MAX_PIECES = 3
 SPLIT_NPROD = (0, 1, 3, 6)
@@ -56,7 +56,7 @@ class Split(C.Structure):
 
 
 class NormFusion(C.Structure):
-    _fields_ = [("xb_out", vp), ("ss_out", vp), ("ss_in", vp), ("nblk_in", i32), ("d", i32), ("eps", f32)]
+    _fields_ = [("xb_out", vp), ("ss_out", vp), ("ss_in", vp), ("nblk_in", i32), ("d", i32), ("eps", f32), ("quarter", i32)]
 
 
 class Compaction(C.Structure):
@@ -109,6 +109,7 @@ SIGNATURES = {
     "gram_encode_fused": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, C.c_int, vp, vp]),
     "gram_decode_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
     "gram_debug_set_gemm_variant": (C.c_int, [C.c_int]),
+    "gram_gemm_stream_max_m": (C.c_int, []),
     "gram_debug_set_live_rows": (C.c_int, [C.c_int]),
     "gram_debug_set_graph": (C.c_int, [C.c_int]),
     "gram_debug_stream_read": (C.c_int, [vp, C.c_size_t, vp, vp]),

@@ -54,6 +54,7 @@ struct EpiArgs {
   float* ss_out;       // producer: [M][N/64] partial sums of squares
   const float* ss_in;  // consumer: [M][ss_nblk] partials of A's rows
   int ss_nblk, ss_out_nblk;
+  int ss_quarter;  // partials per 16 columns ([M][4 * nblk]) instead of per 64: the layout of gemm_stream_kernel (gram_norm_fusion_t.quarter)
   float inv_d, eps;
   // KV bank
   bf16* bank_k;
@@ -522,6 +523,259 @@ int launch_skinny(const void* A, const void* W, int M, int N, int K, int lda, Ep
   return 0;
 }
 
+// LDS-DMA issued through inline asm: with the builtin, hipcc treats the DMA as an LDS store that may
+// alias every pending ds_read and puts s_waitcnt lgkmcnt(0) in front of it, which serialises the fragment
+// prefetch this kernel is built around.  The asm form is invisible to the waitcnt pass, so the kernel waits
+// for its DMA explicitly (counted s_waitcnt vmcnt) before the barrier that publishes a buffer.
+__device__ __forceinline__ void dma16_asm(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
+}
+__device__ __forceinline__ void dma4_asm(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
+}
+
+// ---------------------------------------------------------------------------------------------
+// M <= 64, second generation: gemm_skinny_kernel keeps 8 KiB of W in flight per wave, so an N = 768 problem (48 waves)
+// streams its weights at ~0.3 TB/s and a one-user generate() -- a chain of ~600 such GEMMs -- spends 2/3 of its time
+// there (rocprofv3, B = 1: 80 us for the FFN-out of the bf16x3 mode).  Here a WORKGROUP owns one 16-column n-tile and
+// 16*MT rows, and its whole LDS is a ring of NS stages filled by LDS-DMA: a stage = 128 reduction columns of the W
+// rows (16 x 256 B) and of the A rows (MT x 16 x 256 B), one DMA instruction per wave and tile; 50-76 KiB of W in
+// flight per workgroup and as many workgroups as the launch can place (<= 256: one per CU).  Wave j < MT multiplies
+// m-tile j: the SAME MFMA sequence per accumulator as every tiled kernel (k-blocks in order, chunk after chunk), so the
+// results are bit-identical to theirs.  One barrier per stage publishes the landed stage and frees the consumed one.
+// The sum-of-squares partials of the folded T5LayerNorm cover 16 columns here (`quarter` layout of
+// gram_norm_fusion_t): the butterfly of the 64-column epilogues is (q0 + q1) + (q2 + q3) over exactly these quarters, and the
+// consumer adds them in that order.
+template <int MT>
+struct StreamCfg {
+  static constexpr int NS = MT == 1 ? 19 : MT == 2 ? 13 : 7;  // 152 / 156 / 140 KiB
+  static constexpr int SB = 4096 * (1 + MT);
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// at most Q * later DMAs of this wave may still be in flight
+template <int Q>
+__device__ __forceinline__ void wait_later(int later) {
+#define GRAM_WL(n) \
+  case n: wait_vmcnt<(Q * n <= 63 ? Q * n : 63)>(); break;
+  switch (later) {
+    GRAM_WL(1) GRAM_WL(2) GRAM_WL(3) GRAM_WL(4) GRAM_WL(5) GRAM_WL(6) GRAM_WL(7) GRAM_WL(8) GRAM_WL(9) GRAM_WL(10)
+    GRAM_WL(11) GRAM_WL(12) GRAM_WL(13) GRAM_WL(14) GRAM_WL(15) GRAM_WL(16) GRAM_WL(17)
+    default: wait_vmcnt<0>(); break;
+  }
+#undef GRAM_WL
+}
+
+// 1/rms of row m of A for the streaming kernel: the partials' loads go out together (row_rscale's loop waits for each), the sums
+// are row_rscale's -- pairs of 64-column blocks in order; a block of the quarter layout is (q0 + q1) + (q2 + q3)
+__device__ __forceinline__ float row_rscale_stream(const EpiArgs& ep, int m) {
+  if (ep.ss_nblk == 0) return ep.ss_in[m];  // already 1/rms
+  float s = 0.f;
+  const int npair = ep.ss_nblk / 2;
+  if (ep.ss_quarter) {
+    const float4* p = reinterpret_cast<const float4*>(ep.ss_in + (size_t)m * ep.ss_nblk * 4);
+    for (int i0 = 0; i0 < npair; i0 += 4) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[min(2 * i0 + u, ep.ss_nblk - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u < npair) {
+          const float pa = (v[2 * u].x + v[2 * u].y) + (v[2 * u].z + v[2 * u].w);
+          const float pb = (v[2 * u + 1].x + v[2 * u + 1].y) + (v[2 * u + 1].z + v[2 * u + 1].w);
+          s += pa + pb;
+        }
+    }
+  } else {
+    const float2* p = reinterpret_cast<const float2*>(ep.ss_in + (size_t)m * ep.ss_nblk);
+    for (int i0 = 0; i0 < npair; i0 += 8) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[min(i0 + u, npair - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < npair) s += v[u].x + v[u].y;
+    }
+  }
+  return rsqrtf(s * ep.inv_d + ep.eps);
+}
+
+template <int EPI, int MT>
+__global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
+                                                          int K, int lda, int G, EpiArgs ep, KSplit ks) {
+  static_assert(EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || EPI == GRAM_EPI_F32_ADD, "stream kernel epilogues");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NS = StreamCfg<MT>::NS, SB = StreamCfg<MT>::SB, Q = 1 + MT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  // workgroup -> (n-tile, row group).  Workgroups are dealt to the 8 XCDs round-robin: the G row groups of an n-tile are 8 ids
+  // apart, i.e. on the same XCD, so its W rows are pulled into one L2
+  const int b = blockIdx.x;
+  const int ntile = (b / (8 * G)) * 8 + (b & 7), rg = (b >> 3) % G;
+  const int n0 = ntile * 16, m0 = rg * (16 * MT);
+  const bool consumer = wave < MT && m0 + wave * 16 < M;
+
+  // DMA lane map: this wave fills rows 4*wave .. +3 of every tile; slot (lane & 15) of row dr receives chunk slot ^ dr
+  const int dr = wave * 4 + (lane >> 4);
+  const int dch = (lane & 15) ^ dr;
+  const uint32_t w_off = (uint32_t)dr * (uint32_t)K * 2u + (uint32_t)dch * 16u;
+  uint32_t a_off[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) a_off[j] = (uint32_t)min(m0 + 16 * j + dr, M - 1) * (uint32_t)lda * 2u + (uint32_t)dch * 16u;
+  const char* wsrc = reinterpret_cast<const char*>(W + (size_t)n0 * K);  // advances 256 B per issued stage
+  const char* abase = reinterpret_cast<const char*>(A);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+  const int nst = K >> 7;  // stages of 128 reduction columns (kc % 128 == 0: a stage never straddles two chunks)
+  int i_slot = 0, i_c = 0, i_kk = 0;  // cursor of the next stage to issue: ring slot, chunk, column inside the chunk
+  long i_acol = ks_acol(ks, 0);
+  auto issue = [&]() {
+    const uint32_t dst = wave_lds + (uint32_t)i_slot * SB;
+    dma16_asm(dst, w_off, wsrc);
+    const char* asrc = abase + (i_acol + i_kk) * 2;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) dma16_asm(dst + 4096 * (1 + j), a_off[j], asrc);
+    wsrc += 256;
+    i_slot = i_slot + 1 == NS ? 0 : i_slot + 1;
+    i_kk += 128;
+    if (i_kk == ks.kc) {
+      i_kk = 0;
+      ++i_c;
+      i_acol = ks_acol(ks, i_c);
+    }
+  };
+  const int npro = min(NS - 1, nst);
+  for (int st = 0; st < npro; ++st) issue();
+
+  float rs = 1.f;
+  if constexpr (EPI != GRAM_EPI_F32_ADD) {
+    if (consumer && ep.ss_in) rs = row_rscale_stream(ep, min(m0 + wave * 16 + r16, M - 1));
+    asm volatile("" : "+v"(rs));  // (the partials' loads are waited for here, behind the first DMAs, not in the epilogue)
+  }
+
+  // fragment reads: lane (r16, g) takes chunk 4*kb + g of tile row r16
+  int foff[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) foff[kb] = r16 * 256 + (((kb * 4 + g) ^ r16) << 4);
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 fw0[4], fa0[4], fw1[4], fa1[4];  // fragments of the stage being read and of the one being multiplied (one stage behind)
+  int c_slot = 0;
+  auto read_frags = [&](bf16x8 (&fw)[4], bf16x8 (&fa)[4]) {
+    const char* sw = smem + c_slot * SB;
+    const char* sa = sw + 4096 * (1 + wave);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      fw[kb] = *reinterpret_cast<const bf16x8*>(sw + foff[kb]);
+      fa[kb] = *reinterpret_cast<const bf16x8*>(sa + foff[kb]);
+    }
+    c_slot = c_slot + 1 == NS ? 0 : c_slot + 1;
+  };
+  auto mfmas = [&](const bf16x8 (&fw)[4], const bf16x8 (&fa)[4]) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) acc = mfma16(fw[kb], fa[kb], acc);
+  };
+  // Stage st: wait for this wave's part of it, barrier (everyone's part has landed; stage st - 1 has been read: the barrier's
+  // lgkmcnt(0)), read its fragments, refill the slot of stage st - 1, multiply stage st - 1 while the reads are in flight.
+  auto step = [&](int st, bool steady, bf16x8 (&cw)[4], bf16x8 (&ca)[4], const bf16x8 (&pw)[4], const bf16x8 (&pa)[4]) {
+    if (steady) wait_vmcnt<(Q * (NS - 2) <= 63 ? Q * (NS - 2) : 63)>();
+    else wait_later<Q>(nst - 1 - st);
+    __syncthreads();
+    if (consumer) read_frags(cw, ca);
+    if (st + NS - 1 < nst) issue();
+    if (consumer && st > 0) mfmas(pw, pa);
+  };
+  const int n_steady = nst - (NS - 1) > 0 ? nst - (NS - 1) : 0;  // stages with NS - 2 later stages in flight behind them
+  int st = 0;
+  for (; st + 1 < n_steady; st += 2) {
+    step(st, true, fw0, fa0, fw1, fa1);
+    step(st + 1, true, fw1, fa1, fw0, fa0);
+  }
+  for (; st < nst; ++st) {
+    const bool steady = st < n_steady;
+    if (st & 1) step(st, steady, fw1, fa1, fw0, fa0);
+    else step(st, steady, fw0, fa0, fw1, fa1);
+  }
+  if (!consumer) return;
+  if ((nst - 1) & 1) mfmas(fw1, fa1);
+  else mfmas(fw0, fa0);
+  const int m = m0 + wave * 16 + r16, n = n0 + 4 * g;
+  const bool row_ok = m < M;
+  if constexpr (EPI == GRAM_EPI_F32_ADD) {
+    float ssq = 0.f;
+    if (row_ok) {
+      f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n);
+      f32x4 val = acc;
+      val += *pc;
+      *pc = val;
+      if (ep.xb_out) {
+        f32x4 rem = val;
+        for (int p = 0; p < ep.split; ++p) {
+          const uint2 pk = pack_bf16x4(rem);
+          *reinterpret_cast<uint2*>(ep.xb_out + p * ep.xb_pstride + (size_t)m * ep.ldc + n) = pk;
+          rem -= unpack_bf16x4(pk);
+        }
+        ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
+      }
+    }
+    if (ep.ss_out) {  // (wave-uniform) the first two butterfly steps of the 64-column epilogues: the 4 lanes of a row in this n-tile
+      ssq += __shfl_xor(ssq, 16, 64);
+      ssq += __shfl_xor(ssq, 32, 64);
+      if (g == 0 && row_ok) ep.ss_out[(size_t)m * ep.ss_out_nblk + ntile] = ssq;
+    }
+  } else {
+    f32x4 v = acc * rs;
+    if constexpr (EPI == GRAM_EPI_BF16_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    for (int p = 0; p < ep.split; ++p) {
+      const uint2 pk = pack_bf16x4(v);
+      if (row_ok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(ep.C) + p * ep.c_pstride + (size_t)m * ep.ldc + n) = pk;
+      if (p + 1 < ep.split) v -= unpack_bf16x4(pk);
+    }
+  }
+}
+
+constexpr int kStreamMaxMLimit = 4096;  // (the callers size their quarter-partial buffers for this many rows)
+int stream_max_m() {  // rows up to which the streaming kernel is used; 0 = off (GRAM_GEMM_STREAM_MAXM: A/B hook)
+  static const int v = [] {
+    const char* e = getenv("GRAM_GEMM_STREAM_MAXM");
+    const int x = e ? atoi(e) : 1024;
+    return x < 0 ? 0 : x > kStreamMaxMLimit ? kStreamMaxMLimit : x;
+  }();
+  return v;
+}
+bool stream_enabled() { return stream_max_m() > 0; }
+
+template <int EPI, int MT>
+int launch_stream_mt(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
+  constexpr int smem = StreamCfg<MT>::NS * StreamCfg<MT>::SB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int G = (M + 16 * MT - 1) / (16 * MT);
+  hipLaunchKernelGGL((gemm_stream_kernel<EPI, MT>), dim3((N / 16) * G), dim3(256), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, G, ep, ks);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+// rows per workgroup: as few as keep the launch within one workgroup per CU (more workgroups = more W in flight)
+template <int EPI>
+int launch_stream(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
+  if (M < 1 || M > kStreamMaxMLimit || N % 128 || ks.kc % 128) return GRAM_E_ARG;
+  const int nt = N / 16;
+  if (nt * ((M + 15) / 16) <= 256) return launch_stream_mt<EPI, 1>(A, W, M, N, K, lda, ep, ks, st);
+  if (nt * ((M + 31) / 32) <= 256) return launch_stream_mt<EPI, 2>(A, W, M, N, K, lda, ep, ks, st);
+  return launch_stream_mt<EPI, 4>(A, W, M, N, K, lda, ep, ks, st);
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int EPI, int WM, int NST, int TNW>
 __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void gemm_dma_kernel(
@@ -611,17 +865,6 @@ __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-DMA issued through inline asm: with the builtin, hipcc treats the DMA as an LDS store that may
-// alias every pending ds_read and puts s_waitcnt lgkmcnt(0) in front of it, which serialises the fragment
-// prefetch this kernel is built around.  The asm form is invisible to the waitcnt pass, so the kernel waits
-// for its DMA explicitly (counted s_waitcnt vmcnt) before the barrier that publishes a buffer.
-__device__ __forceinline__ void dma16_asm(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
-}
-__device__ __forceinline__ void dma4_asm(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
-}
-
 // ---------------------------------------------------------------------------------------------
 // V_PP: persistent 256x256 "ping-pong" kernel.  8 waves = 2 groups (wr = wave >> 2) x 4 column slices
 // (wc = wave & 3); a wave owns 128 rows x 64 columns = 4 quadrants of 64 x 32.  A k-tile (BK = 64) is
@@ -1592,11 +1835,17 @@ int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiAr
   return 0;
 }
 
-constexpr int V_SKINNY = 30;
+constexpr int V_SKINNY = 30, V_STREAM = 32;
 
 template <int EPI>
 int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
   gram_prof::Scope prof(GRAM_K_GEMM, st, 2.0 * M * N * K);  // K = the executed reduction length (np * kc for split operands)
+  if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || EPI == GRAM_EPI_F32_ADD) {
+    // one user (or a few): the streaming kernel.  A producer of 64-column sum-of-squares partials stays on the older skinny kernel.
+    const bool fits = M <= stream_max_m() && N % 128 == 0 && ks.kc % 128 == 0 && (EPI != GRAM_EPI_F32_ADD || !ep.ss_out || ep.ss_quarter);
+    if (g_force_variant == V_STREAM || (g_force_variant < 0 && stream_enabled() && fits)) return launch_stream<EPI>(A, W, M, N, K, lda, ep, ks, st);
+  }
+  if (ep.ss_quarter) return GRAM_E_ARG;  // (only the streaming kernel reads / writes that layout)
   if constexpr (EPI != GRAM_EPI_KV_BANK) {
     static const int use_skinny = getenv("GRAM_GEMM_SKINNY") ? atoi(getenv("GRAM_GEMM_SKINNY")) : 1;  // A/B hook
     static const int skinny_max_m = getenv("GRAM_GEMM_SKINNY_MAXM") ? atoi(getenv("GRAM_GEMM_SKINNY_MAXM")) : 64;  // A/B hook
@@ -1653,6 +1902,8 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
 }
 
 }  // namespace
+
+extern "C" int gram_gemm_stream_max_m(void) { return g_force_variant < 0 ? stream_max_m() : 0; }
 
 extern "C" int gram_debug_set_gemm_variant(int v) {
   if (v >= 1000) {  // 1000 + s: set the persistent kernel's start stagger instead
@@ -1737,11 +1988,13 @@ extern "C" int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M
       if ((nf->xb_out == nullptr) != (nf->ss_out == nullptr)) return GRAM_E_ARG;
       ep.xb_out = (bf16*)nf->xb_out;
       ep.ss_out = nf->ss_out;
-      ep.ss_out_nblk = N / 64;
+      ep.ss_quarter = nf->quarter != 0 && nf->ss_out;
+      ep.ss_out_nblk = ep.ss_quarter ? N / 16 : N / 64;
     } else if (epilogue == GRAM_EPI_BF16 || epilogue == GRAM_EPI_BF16_RELU) {
       if (nf->ss_in && nf->nblk_in != 0 && (nf->nblk_in < 2 || (nf->nblk_in & 1) || nf->d < 64)) return GRAM_E_ARG;
       ep.ss_in = nf->ss_in;
       ep.ss_nblk = nf->nblk_in;
+      ep.ss_quarter = nf->quarter != 0 && nf->ss_in && nf->nblk_in != 0;
       ep.inv_d = 1.0f / (float)nf->d;
       ep.eps = nf->eps;
     } else if (nf->xb_out || nf->ss_out || nf->ss_in) {

@@ -52,6 +52,7 @@ struct Carve {
 
 constexpr int64_t kGraphMaxRows = 4096;  // B*K up to which generate() is replayed from a HIP graph (GRAM_GRAPH=0: never)
 
+constexpr int kQuarterRows = 4096;  // >= gram_gemm_stream_max_m() always: rows up to which the sum-of-squares buffers hold 16-column partials
 struct Workspace {
   // encoder
   float* x;         // [Me][d]   residual stream (fp32)
@@ -118,7 +119,7 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   w.qkv = cv.take<bf16>(P * w.ps_qkv);
   w.attn = cv.take<bf16>(P * w.ps_attn);
   w.u = cv.take<bf16>(P * w.ps_u);
-  w.ss = cv.take<float>(Me * (d / 64));
+  w.ss = cv.take<float>(Me <= kQuarterRows ? Me * (d / 16) : Me * (d / 64));
   w.rs = cv.take<float>(Me);
   w.bank_k = cv.take<bf16>(P * w.ps_bank);
   w.bank_vt = cv.take<bf16>(P * w.ps_bank);
@@ -128,7 +129,7 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   w.attnd = cv.take<bf16>(P * w.ps_attnd);
   w.qx = cv.take<bf16>(P * w.ps_qx);
   w.ud = cv.take<bf16>(P * w.ps_ud);
-  w.ssd = cv.take<float>(R * (d / 64));
+  w.ssd = cv.take<float>(R <= kQuarterRows ? R * (d / 16) : R * (d / 64));  // (16-column partials for a small-M step: gram_norm_fusion_t.quarter)
   w.rsd = cv.take<float>(R);
   w.kcache = cv.take<bf16>(P * w.ps_cache);
   w.vcache = cv.take<bf16>(P * w.ps_cache);
@@ -202,17 +203,21 @@ int encoder_layers(const gram_model* m, const Workspace& w, const int64_t* ids, 
   if (c.fold_norm) {
     // T5LayerNorm folded into the GEMMs around it (gram_norm_fusion_t): w.h holds xb = bf16(x), w.ss the
     // per-row sum-of-squares partials; both are refreshed by every residual GEMM's epilogue
-    const gram_norm_fusion_t produce{w.h, w.ss, nullptr, 0, 0, 0.f};
+    // few rows (one short user): the streaming GEMM and its 16-column partials (gram_norm_fusion_t.quarter); the embedding writes 64-column ones
+    const int quarter = Me <= gram_gemm_stream_max_m() && d % 128 == 0 && inner % 128 == 0 && F % 128 == 0;
+    const gram_norm_fusion_t produce{w.h, w.ss, nullptr, 0, 0, 0.f, quarter};
     // big problems (the ping-pong GEMMs, M >= kPrecomputedRsRows) take 1/rms precomputed per row by one tiny kernel per
     // norm; below that the consumer GEMM adds the partials itself (same order, same bits) and the launch is saved --
     // a small batch is a chain of ~1 500 dependent launches and nothing else
     const bool pre_rs = Me >= kPrecomputedRsRows;
     const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rs, 0, d, c.eps}
-                                              : gram_norm_fusion_t{nullptr, nullptr, w.ss, d / 64, d, c.eps};
+                                              : gram_norm_fusion_t{nullptr, nullptr, w.ss, d / 64, d, c.eps, quarter};
+    const gram_norm_fusion_t consume_embed{nullptr, nullptr, w.ss, d / 64, d, c.eps, 0};
     TRY(gram_embed_ex_split(c.embed_f32, ids, 1, w.x, w.h, w.ss, d / 64, Me, d, w.pieces, w.ps_h, st));
     for (int i = 0; i < c.n_enc_layers; ++i) {
       if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
-      TRY(linear(w, w.h, w.ps_h, m->enc_wqkv[i], w.qkv, w.ps_qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
+      TRY(linear(w, w.h, w.ps_h, m->enc_wqkv[i], w.qkv, w.ps_qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr,
+                 i == 0 && !pre_rs ? &consume_embed : &consume, st));
       TRY(gram_enc_self_attn_split(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, w.pieces, w.ps_qkv, w.ps_attn, st));
       TRY(linear(w, w.attn, w.ps_attn, m->enc_wo[i], w.x, w.ps_h, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
@@ -287,14 +292,18 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   const size_t bank_layer = (size_t)B * H * S * 64;
   const size_t cache_layer = (size_t)Tmax * R_cache * inner;
   if (c.fold_norm) {
-    const gram_norm_fusion_t produce{w.hd, w.ssd, nullptr, 0, 0, 0.f};
+    // a few rows (one user, or a handful): the streaming GEMM and its 16-column partials; the embedding writes 64-column ones
+    const int quarter = R <= gram_gemm_stream_max_m() && d % 128 == 0 && inner % 128 == 0 && F % 128 == 0;
+    const gram_norm_fusion_t produce{w.hd, w.ssd, nullptr, 0, 0, 0.f, quarter};
     const bool pre_rs = R >= kPrecomputedRsRows;  // see encoder_layers
-    const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rsd, 0, d, c.eps}
-                                              : gram_norm_fusion_t{nullptr, nullptr, w.ssd, d / 64, d, c.eps};
+    const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rsd, 0, d, c.eps, 0}
+                                              : gram_norm_fusion_t{nullptr, nullptr, w.ssd, d / 64, d, c.eps, quarter};
+    const gram_norm_fusion_t consume_embed{nullptr, nullptr, w.ssd, d / 64, d, c.eps, 0};
     TRY(gram_embed_ex_split(c.embed_f32, tokens, 0, w.xd, w.hd, w.ssd, d / 64, R, d, w.pieces, w.ps_hd, st));
     for (int i = 0; i < c.n_dec_layers; ++i) {
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
-      TRY(linear(w, w.hd, w.ps_hd, m->dec_wqkv[i], w.qkvd, w.ps_qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, &consume, st));
+      TRY(linear(w, w.hd, w.ps_hd, m->dec_wqkv[i], w.qkvd, w.ps_qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr,
+                 i == 0 && !pre_rs ? &consume_embed : &consume, st));
       TRY(self_attn(i, cache_layer));
       TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo[i], w.xd, w.ps_hd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GRAM_ABI_VERSION 3
+#define GRAM_ABI_VERSION 4
 
 #define GRAM_E_ARG (-1)       /* bad shape / unsupported size                           */
 #define GRAM_E_WORKSPACE (-2) /* workspace too small (see gram_workspace_bytes)          */
@@ -80,7 +80,13 @@ typedef struct {
   int32_t nblk_in;     /* consumer: d_model / 64, or 0 if ss_in already holds 1/rms per row        */
   int32_t d;           /* consumer: d_model (the mean is over d elements)                          */
   float eps;
+  int32_t quarter;     /* != 0: the partials cover 16 columns each -- ss_out [M][N/16], ss_in [M][4*nblk_in] -- and a block's
+                          sum is (q0 + q1) + (q2 + q3), which is how the 64-column epilogues add it up themselves: same bits.
+                          The layout of the small-M streaming GEMM (one 16-column n-tile per workgroup); only legal for
+                          M <= gram_gemm_stream_max_m() and K % 128 == 0 (GRAM_E_ARG otherwise)                  */
 } gram_norm_fusion_t;
+/* Largest M the streaming small-M GEMM takes (0: switched off, GRAM_GEMM_STREAM=0 or a forced variant). */
+int gram_gemm_stream_max_m(void);
 int gram_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, int epilogue,
                       const gram_kv_bank_t* bank_host, const gram_norm_fusion_t* nf_host, void* stream);
 /* rs[m] = rsqrt(sum_b ss[m][b] / d + eps); a consumer may take it directly with nblk_in = 0 (ss_in = rs). */

@@ -353,3 +353,74 @@ def test_split_gemm_kv_bank_persistent(G, pieces, compact):
         L_.gram_debug_set_gemm_variant(-1)
     assert res[22][0].abs().sum() > 0
     assert torch.equal(res[3][0], res[22][0]) and torch.equal(res[3][1], res[22][1])
+
+
+@pytest.mark.parametrize("pieces", [1, 2, 3])
+@pytest.mark.parametrize("M", [1, 16, 20, 33, 64, 100, 384])
+@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (768, 3072), (1408, 512), (256, 128)])
+def test_gemm_stream_matches_tiled(G, pieces, M, N, K):
+    """The small-M streaming kernel (variant 32: one 16-column n-tile per workgroup, W and A through an LDS ring filled by
+    LDS-DMA) against the tiled 128 x 128 kernel (variant 1), bit for bit, plain and split operands: bf16 / bf16+ReLU with
+    the folded-norm row scale from 64-column AND from 16-column ("quarter") partials, the fp32 residual add, and the
+    producer outputs -- the residual, its bf16 pieces, and quarter partials whose (q0 + q1) + (q2 + q3) are the tiled
+    kernel's 64-column partials."""
+    from gram_amd import _lib
+    L_ = G.lib()
+    a32, w32 = _r(M, K, seed=31).to(G.DEV), _r(N, K, seed=32, scale=K ** -0.5).to(G.DEV)
+    A, W = pieces_of(a32, pieces), expand_w(w32, pieces)
+    sp = _lib.Split(pieces, M * K, M * N, M * N, 0)
+    q_in = (torch.rand(M, K // 16, generator=torch.Generator().manual_seed(33)) * 16 + 0.25).to(G.DEV)
+    q4 = q_in.view(M, K // 64, 4)
+    ss_in = ((q4[..., 0] + q4[..., 1]) + (q4[..., 2] + q4[..., 3])).contiguous()  # fp32, the order the epilogues use
+    base = _r(M, N, seed=34).to(G.DEV)
+    outs = {}
+    try:
+        for v in (1, 32):
+            L_.gram_debug_set_gemm_variant(v)
+            o = {}
+            for epi in (_lib.EPI_BF16, _lib.EPI_BF16_RELU):
+                y = torch.zeros(pieces, M, N, dtype=torch.bfloat16, device=G.DEV)
+                _lib.check(L_.gram_gemm_bf16_split(G.p(A), G.p(W), G.p(y), M, N, K, K, N, epi, None, None, C.byref(sp), G.stream()), "plain")
+                o[("plain", epi)] = y
+                y2 = torch.zeros(pieces, M, N, dtype=torch.bfloat16, device=G.DEV)
+                cons = _lib.NormFusion(None, None, ss_in.data_ptr(), K // 64, K, 1e-6)
+                _lib.check(L_.gram_gemm_bf16_split(G.p(A), G.p(W), G.p(y2), M, N, K, K, N, epi, None, C.byref(cons), C.byref(sp), G.stream()), "consumer")
+                o[("scaled", epi)] = y2
+                if v == 32:
+                    y3 = torch.zeros(pieces, M, N, dtype=torch.bfloat16, device=G.DEV)
+                    cons = _lib.NormFusion(None, None, q_in.data_ptr(), K // 64, K, 1e-6, 1)
+                    _lib.check(L_.gram_gemm_bf16_split(G.p(A), G.p(W), G.p(y3), M, N, K, K, N, epi, None, C.byref(cons), C.byref(sp), G.stream()), "quarter consumer")
+                    o[("quarter", epi)] = y3
+            x0 = base.clone()
+            _lib.check(L_.gram_gemm_bf16_split(G.p(A), G.p(W), G.p(x0), M, N, K, K, N, _lib.EPI_F32_ADD, None, None, C.byref(sp), G.stream()), "add")
+            o["add_plain"] = x0
+            x = base.clone()
+            xb = torch.zeros(pieces, M, N, dtype=torch.bfloat16, device=G.DEV)
+            quarter = v == 32
+            ss = torch.full((M, N // (16 if quarter else 64)), float("nan"), dtype=torch.float32, device=G.DEV)
+            prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0, int(quarter))
+            _lib.check(L_.gram_gemm_bf16_split(G.p(A), G.p(W), G.p(x), M, N, K, K, N, _lib.EPI_F32_ADD, None, C.byref(prod), C.byref(sp), G.stream()), "producer")
+            if quarter:
+                s4 = ss.view(M, N // 64, 4)
+                ss = (s4[..., 0] + s4[..., 1]) + (s4[..., 2] + s4[..., 3])
+            o["add"], o["xb"], o["ss"] = x, xb, ss
+            torch.cuda.synchronize()
+            outs[v] = o
+    finally:
+        L_.gram_debug_set_gemm_variant(-1)
+    ref = a32.double() @ w32.double().T
+    tol = {1: 2e-2, 2: TOL[2], 3: TOL[3]}[pieces]
+    if pieces > 1:
+        assert relerr(outs[32]["add_plain"], base.double() + ref) < tol
+    for key in outs[1]:
+        assert torch.equal(outs[1][key], outs[32][key]), key
+    for epi in (_lib.EPI_BF16, _lib.EPI_BF16_RELU):
+        assert torch.equal(outs[32][("quarter", epi)], outs[1][("scaled", epi)]), ("quarter", epi)
+    # not on the streaming kernel: a quarter layout is refused, not misread
+    L_.gram_debug_set_gemm_variant(1)
+    try:
+        y = torch.zeros(pieces, M, N, dtype=torch.bfloat16, device=G.DEV)
+        cons = _lib.NormFusion(None, None, q_in.data_ptr(), K // 64, K, 1e-6, 1)
+        assert L_.gram_gemm_bf16_split(G.p(A), G.p(W), G.p(y), M, N, K, K, N, _lib.EPI_BF16, None, C.byref(cons), C.byref(sp), G.stream()) == _lib.E_ARG
+    finally:
+        L_.gram_debug_set_gemm_variant(-1)
