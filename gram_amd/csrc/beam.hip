@@ -169,7 +169,33 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
         // split-bf16 modes (gram_split_t): h = fp32 sum of its pieces (smallest first), E = the fp32 lm_head row
         const bf16* hp = hd + (size_t)lr * d + sub * per;
         const f32x4* ep = reinterpret_cast<const f32x4*>(emb32 + (size_t)tok * d + sub * per);
-        for (int i = 0; i < per; i += 8) {
+        int i = 0;
+        if (pieces <= 2) {
+          // 32 elements per lane and trip, every load of the trip in flight together (one 8-element step per trip is a dependent
+          // round trip each: 12 of them per candidate at d = 768); same sums in the same order as the loop below
+          for (; i + 32 <= per; i += 32) {
+            bf16x8 hb0[4], hb1[4];
+            f32x4 ev[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              hb0[u] = ld_global_b128(hp + i + 8 * u);
+              hb1[u] = pieces == 2 ? ld_global_b128(hp + hd_pstride + i + 8 * u) : zero_bf16x8();
+              ev[2 * u] = ep[(i >> 2) + 2 * u];
+              ev[2 * u + 1] = ep[(i >> 2) + 2 * u + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              float hv[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) hv[e] = pieces == 2 ? (0.f + (float)hb1[u][e]) + (float)hb0[u][e] : 0.f + (float)hb0[u][e];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc += hv[e] * ev[2 * u][e];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc += hv[4 + e] * ev[2 * u + 1][e];
+            }
+          }
+        }
+        for (; i < per; i += 8) {
           float hv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           for (int pc = pieces - 1; pc >= 0; --pc) {
             const bf16x8 hb = ld_global_b128(hp + pc * hd_pstride + i);
