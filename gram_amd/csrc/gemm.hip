@@ -37,7 +37,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
-enum { V_DMA_M64 = 31, V_REG2 = 0, V_DMA = 1, V_DMA_M256 = 3, V_PP = 22 };  // (ids kept from the variant table of round 1)
+enum { V_DMA_M64 = 31, V_REG2 = 0, V_DMA = 1, V_DMA_M256 = 3, V_PP = 22, V_RING_M64 = 33, V_RING_M128 = 34 };  // (ids kept from the variant table of round 1)
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
 int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain)
 
@@ -744,7 +744,7 @@ constexpr int kStreamMaxMLimit = 4096;  // (the callers size their quarter-parti
 int stream_max_m() {  // rows up to which the streaming kernel is used; 0 = off (GRAM_GEMM_STREAM_MAXM: A/B hook)
   static const int v = [] {
     const char* e = getenv("GRAM_GEMM_STREAM_MAXM");
-    const int x = e ? atoi(e) : 1024;
+    const int x = e ? atoi(e) : 512;  // measured: above ~500 rows the deep-ring tiles win (tests/bench_small_batch.py)
     return x < 0 ? 0 : x > kStreamMaxMLimit ? kStreamMaxMLimit : x;
   }();
   return v;
@@ -778,7 +778,7 @@ int launch_stream(const void* A, const void* W, int M, int N, int K, int lda, Ep
 
 // ---------------------------------------------------------------------------------------------
 template <int EPI, int WM, int NST, int TNW>
-__global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void gemm_dma_kernel(
+__global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void gemm_dma_kernel(
     const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks) {
   // WM x 2 waves, block tile (64*WM) x 128.  NST = 1: single LDS stage, latency hidden by the other
   // resident workgroups.  NST = 2: the DMA of k-tile kt+1 is issued before the MFMAs of k-tile kt and
@@ -837,6 +837,59 @@ __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void
 
   const int nkt = K / BK;
   float rs4[4];
+  if constexpr (NST >= 3) {
+    // Few workgroups (at most one per CU, gridDim <= 256): nothing else is resident to hide a single stage's latency, so the
+    // workgroup's LDS is a ring of NST stages filled NST - 1 k-tiles ahead (asm DMA + counted vmcnt as in gemm_stream_kernel;
+    // one barrier per k-tile publishes the landed stage and frees the one just consumed).  Same MFMA order, same epilogues.
+    constexpr int Q = AG + WG;
+    static_assert(Q * (NST - 2) <= 63, "counted vmcnt");
+    const char* abase = reinterpret_cast<const char*>(A + (size_t)m0 * lda);
+    const char* wbase = reinterpret_cast<const char*>(W + (size_t)n0 * K);
+    uint32_t a_off[AG], w_off[WG];
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+      const int row = (wave * AG + i) * 8 + (lane >> 3);
+      a_off[i] = (uint32_t)(min(m0 + row, M - 1) - m0) * (uint32_t)lda * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < WG; ++i) {
+      const int row = (wave * WG + i) * 8 + (lane >> 3);
+      w_off[i] = (uint32_t)row * (uint32_t)K * 2u + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    int i_slot = 0, i_c = 0, i_kk = 0, i_kt = 0;  // cursor of the next k-tile to issue
+    long i_acol = ks_acol(ks, 0);
+    auto issue = [&]() {
+      const uint32_t sa = lds0 + (uint32_t)i_slot * STAGE, sw = sa + A_BYTES;
+      const char* asrc = abase + (i_acol + i_kk) * 2;
+      const char* wsrc = wbase + (size_t)i_kt * (BK * 2);
+#pragma unroll
+      for (int i = 0; i < AG; ++i) dma16_asm(sa + (uwave * AG + i) * 1024, a_off[i], asrc);
+#pragma unroll
+      for (int i = 0; i < WG; ++i) dma16_asm(sw + (uwave * WG + i) * 1024, w_off[i], wsrc);
+      ++i_kt;
+      i_slot = i_slot + 1 == NST ? 0 : i_slot + 1;
+      i_kk += BK;
+      if (i_kk == ks.kc) {
+        i_kk = 0;
+        ++i_c;
+        i_acol = ks_acol(ks, i_c);
+      }
+    };
+    const int npro = min(NST - 1, nkt);
+    for (int kt = 0; kt < npro; ++kt) issue();
+    load_row_scales(ep, m0 + wm * 64, r16, M, rs4);  // (waited for behind the first DMAs)
+    int c_slot = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      wait_later<Q>(min(NST - 2, nkt - 1 - kt));
+      __syncthreads();
+      if (kt + NST - 1 < nkt) issue();
+      compute_tile<TNW>(smem + c_slot * STAGE, smem + c_slot * STAGE + A_BYTES, wm, wn, r16, g, acc);
+      c_slot = c_slot + 1 == NST ? 0 : c_slot + 1;
+    }
+    __syncthreads();  // (the row-contiguous epilogue re-uses the ring as its patches)
+  } else {
   load_row_scales(ep, m0 + wm * 64, r16, M, rs4);
   if constexpr (NST == 1) {
     for (int kt = 0; kt < nkt; ++kt) {
@@ -855,7 +908,8 @@ __global__ __launch_bounds__(WM * 128, (TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void
       __syncthreads();  // drains DMA(kt+1) and fences the reads of stage st
     }
   }
-  if constexpr ((EPI == GRAM_EPI_F32_ADD || EPI == GRAM_EPI_F32) && TNW == 4 && NST == 1) {
+  }
+  if constexpr ((EPI == GRAM_EPI_F32_ADD || EPI == GRAM_EPI_F32) && TNW == 4 && NST != 2) {
     if (ep.nt & 4) {  // (the last barrier of the k-loop has passed: the stage is free for the 4-KiB patches)
       epilogue_rows64<EPI>(acc, smem + wave * 4096, m0, n0, wm, wn, lane, M, ep);
       return;
@@ -1808,6 +1862,12 @@ int pick_variant(int M, int N, int K) {
   // already wins at 480 tiles (M = 40960, N = 768: 230 us vs 277 us for the 128x128 variant)
   if (N % 256 == 0 && M >= 32768 && (tiles256 >= 2048 || K >= 2048)) return V_PP;
   if (tiles256 >= 2048) return V_DMA_M256;
+  // at most one workgroup per CU: nothing else is resident to hide a DMA's latency -> the deep-ring instantiations (64- or 128-row tiles)
+  static const int use_ring = getenv("GRAM_GEMM_RING") ? atoi(getenv("GRAM_GEMM_RING")) : 1;  // A/B hook
+  if (use_ring) {
+    if ((long)((M + 63) / 64) * (N / BN) <= 256) return V_RING_M64;
+    if ((long)((M + 127) / 128) * (N / BN) <= 256) return V_RING_M128;
+  }
   // few 128 x 128 tiles (a batch of 4 .. ~100 users in the decoder): 64-row tiles double the workgroups that pull the weights
   static const int m64_max = getenv("GRAM_GEMM_M64_MAXTILES") ? atoi(getenv("GRAM_GEMM_M64_MAXTILES")) : 256;  // A/B hook; measured +1-2 % at B = 8 .. 256
   if ((long)((M + 127) / 128) * (N / BN) < m64_max) return V_DMA_M64;
@@ -1864,7 +1924,9 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
       if (r != GRAM_E_ARG) return r;
     }
     const int pv = pick_variant(M, N, K);
-    return pv == V_DMA_M64 ? launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, ks, st)
+    return pv == V_RING_M64    ? launch_dma<EPI, 1, 6>(A, W, M, N, K, lda, ep, ks, st)
+           : pv == V_RING_M128 ? launch_dma<EPI, 2, 4>(A, W, M, N, K, lda, ep, ks, st)
+           : pv == V_DMA_M64   ? launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, ks, st)
            : pv == V_DMA   ? launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, ks, st)
                            : launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, ks, st);
   } else {
@@ -1877,6 +1939,8 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
   switch (pick_variant(M, N, K)) {
     case V_DMA: return launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, ks, st);
     case V_DMA_M64: return launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, ks, st);
+    case V_RING_M64: return launch_dma<EPI, 1, 6>(A, W, M, N, K, lda, ep, ks, st);
+    case V_RING_M128: return launch_dma<EPI, 2, 4>(A, W, M, N, K, lda, ep, ks, st);
     case V_PP:
       if (g_force_variant == V_PP || pp_ok) {
         const int r = pp();

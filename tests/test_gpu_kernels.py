@@ -160,7 +160,8 @@ def test_gemm_skinny_matches_tiled(G, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(100, 768, 768), (1280, 2304, 768), (700, 768, 3072)])
 def test_gemm_64_row_tiles_match_128(G, M, N, K):
-    """Variant 31 (the 128-row kernel's template at 64 x 128 tiles) against variant 1, bit for bit."""
+    """Variant 31 (the 128-row kernel's template at 64 x 128 tiles) and the deep-ring instantiations for grids of at most one
+    workgroup per CU (33: 64-row tiles, 6 stages; 34: 128-row tiles, 4 stages) against variant 1, bit for bit."""
     import ctypes as ct
 
     from gram_amd import _lib
@@ -170,7 +171,7 @@ def test_gemm_64_row_tiles_match_128(G, M, N, K):
     base = _r(M, N, seed=34).to(G.DEV)
     outs = {}
     try:
-        for v in (1, 31):
+        for v in (1, 31, 33, 34):
             L_.gram_debug_set_gemm_variant(v)
             o = {}
             y = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
@@ -191,8 +192,9 @@ def test_gemm_64_row_tiles_match_128(G, M, N, K):
     finally:
         L_.gram_debug_set_gemm_variant(-1)
     assert torch.allclose(outs[31]["add"], base + A.float() @ W.float().T, atol=2e-3, rtol=1e-4)
-    for key in outs[1]:
-        assert torch.equal(outs[1][key], outs[31][key]), key
+    for v in (31, 33, 34):
+        for key in outs[1]:
+            assert torch.equal(outs[1][key], outs[v][key]), (v, key)
 
 
 def test_gemm_asymmetric_identity(G):

@@ -271,11 +271,12 @@ def test_split_generate_vs_oracle(G, mode, tol, name, B, N, L, K):
 
 
 @pytest.mark.parametrize("pieces", [2, 3])
-@pytest.mark.parametrize("M,N,K", [(256 * 40 + 100, 768, 256), (520, 512, 512), (256 * 9, 2304, 768)])
-def test_split_gemm_persistent_matches_tiles(G, pieces, M, N, K):
-    """The persistent ping-pong kernel on split operands (tile-end epilogues, A pieces walked chunk by chunk) against the
-    256x128-tile kernel: same MFMA sequence per accumulator, so every output -- bf16 pieces, fp32, residual + its pieces +
-    sums of squares, LSE partials, the bank -- is compared bit for bit; several tiles per workgroup and an M tail."""
+@pytest.mark.parametrize("M,N,K,variants", [(256 * 40 + 100, 768, 256, (3, 22)), (520, 512, 512, (3, 22)), (256 * 9, 2304, 768, (3, 22)),
+                                            (1280, 768, 768, (3, 33, 34)), (333, 512, 1024, (3, 33, 34))])
+def test_split_gemm_persistent_matches_tiles(G, pieces, M, N, K, variants):
+    """The persistent ping-pong kernel (22) and the deep-ring tiles (33, 34) on split operands (A pieces walked chunk by chunk)
+    against the 256x128-tile kernel: same MFMA sequence per accumulator, so every output -- bf16 pieces, fp32, residual + its
+    pieces + sums of squares, LSE partials -- is compared bit for bit; several tiles per workgroup and an M tail."""
     from gram_amd import _lib
     L_ = G.lib()
     a32, w32 = _r(M, K, seed=11).to(G.DEV), _r(N, K, seed=12, scale=K ** -0.5).to(G.DEV)
@@ -285,7 +286,7 @@ def test_split_gemm_persistent_matches_tiles(G, pieces, M, N, K):
     base = _r(M, N, seed=14).to(G.DEV)
     outs = {}
     try:
-        for v in (3, 22):
+        for v in variants:
             L_.gram_debug_set_gemm_variant(v)
             o = {}
             for epi in (_lib.EPI_BF16, _lib.EPI_BF16_RELU):
@@ -310,9 +311,10 @@ def test_split_gemm_persistent_matches_tiles(G, pieces, M, N, K):
     finally:
         L_.gram_debug_set_gemm_variant(-1)
     ref = a32.double() @ w32.double().T
-    assert relerr(outs[22]["f32"], ref) < TOL[pieces]
-    for key in outs[3]:
-        assert torch.equal(outs[3][key], outs[22][key]), key
+    for v in variants[1:]:
+        assert relerr(outs[v]["f32"], ref) < TOL[pieces]
+        for key in outs[3]:
+            assert torch.equal(outs[3][key], outs[v][key]), (v, key)
 
 
 @pytest.mark.parametrize("pieces", [2, 3])
