@@ -18,7 +18,13 @@
 //   gemm_dma_kernel    global_load_lds (LDS-DMA, 16 B/lane, no staging VGPRs), 1 LDS stage, two barriers per k-tile, up to
 //                      4 workgroups/CU: latency is hidden by the other resident workgroups.  256x128, 128x128 and 64x128
 //                      tiles.  The swizzle is applied to the per-lane SOURCE address (the DMA writes LDS linearly).
-//   gemm_skinny_kernel M <= 64: one 16-column n-tile per wave over the whole K, operands straight from global memory.
+//                      With at most one workgroup per CU (gridDim <= 256: a decoder step of 30 .. 200 users) nothing else is
+//                      resident, and the NST >= 3 instantiations run a ring of 4-6 stages instead (counted vmcnt, one barrier
+//                      per k-tile).
+//   gemm_stream_kernel M <= 512 (one user .. ~25): one 16-column n-tile per WORKGROUP, W and A streamed through a 150-KiB LDS
+//                      ring by LDS-DMA; bf16 / bf16+ReLU / fp32-residual epilogues (16-column sum-of-squares partials).
+//   gemm_skinny_kernel M <= 64: one 16-column n-tile per wave over the whole K, operands straight from global memory
+//                      (what is left on it: the lm_head of a small batch and producers of 64-column partials).
 //   gemm_reg2_kernel   registers -> LDS, 2 LDS stages, loads issued one k-tile ahead (the first correct kernel; kept as
 //                      variant 0 for cross-checks).
 // All of them take split-bf16 operands (gram_split_t / KSplit): the k-loop walks nprod chunks of K, chunk c reading A piece
