@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgram_hip.so")
+LIB_PATH = os.environ.get("GRAM_LIB") or os.path.join(_HERE, "csrc", "libgram_hip.so")  # (GRAM_LIB: an A/B build of the same ABI)
 
 GRAM_MAX_BEAMS = 64
 GRAM_MAX_DEC_LEN = 32
@@ -113,6 +113,7 @@ SIGNATURES = {
     "gram_debug_set_live_rows": (C.c_int, [C.c_int]),
     "gram_debug_set_graph": (C.c_int, [C.c_int]),
     "gram_debug_stream_read": (C.c_int, [vp, C.c_size_t, vp, vp]),
+    "gram_debug_stream_read_variant": (C.c_int, [vp, C.c_size_t, vp, C.c_int, C.c_int, vp]),
     "gram_prof_enable": (C.c_int, [C.c_uint32, C.c_int]),
     "gram_prof_reset": (C.c_int, []),
     "gram_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64)]),

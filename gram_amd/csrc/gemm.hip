@@ -293,7 +293,8 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
             } else {
               const bf16x4 ob = __builtin_bit_cast(bf16x4, o);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) ep.bank_vt[pc * ep.bank_pstride + (head * 64 + d + e) * ep.S + s] = ob[e];
+              for (int e = 0; e < 4; ++e)  // V^T blocked by 32 keys: [head][s / 32][64 d][32]
+                ep.bank_vt[pc * ep.bank_pstride + ((head * (ep.S >> 5) + (s >> 5)) * 64 + d + e) * 32 + (s & 31)] = ob[e];
             }
             v -= unpack_bf16x4(o);
           }
@@ -1400,7 +1401,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // user b and first bank position s0 are wave-uniform.
   struct KVLoc {
     char* kb;  // bank_k + ((head * S + s0) * 64): the block's 32 x 128 B of K
-    char* vb;  // bank_vt + (head * 64 * S + s0): column 0 of the block in V^T
+    char* vb;  // bank_vt + (head * S/32 + s0/32) * 2048: the block's [64 d][32 positions] of V^T (4 KiB, contiguous)
     int mblk;  // first row of the block in A
   };
   auto kv_locate = [&](int tm0, int tn0, int J0) {
@@ -1420,7 +1421,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     const int n = tn0 + wc * 64, lw = (int)udiv_magic((uint32_t)n >> 8, (uint32_t)ep.inner >> 8, ep.mg_it);
     const size_t head = ((size_t)(lw >> 1) * ep.B + b_) * ep.H + ((n - lw * ep.inner) >> 6);
     q.kb = reinterpret_cast<char*>(ep.bank_k + (head * ep.S + s0) * 64);
-    q.vb = reinterpret_cast<char*>(ep.bank_vt + head * 64 * ep.S + s0);
+    q.vb = reinterpret_cast<char*>(ep.bank_vt + (head * (size_t)(ep.S >> 5) + (size_t)(s0 >> 5)) * 2048);
     return q;
   };
   // one (m-tile jj, n-tile pi) fragment of the block straight from registers (8 B per lane)
@@ -1429,7 +1430,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     const u32x2 pk = __builtin_bit_cast(u32x2, pack_bf16x4(v));
     if constexpr (decltype(TRc)::value) {  // lane: column d = pi*16 + lr, rows s0 + jj*16 + 4*lg .. +3
-      const uint32_t off = ((uint32_t)(pi * 16 + lr) * (uint32_t)ep.S + jj * 16 + 4 * lg) * 2u;
+      const uint32_t off = ((uint32_t)(pi * 16 + lr) * 32u + jj * 16 + 4 * lg) * 2u;
       if (q.mblk + jj * 16 + 4 * lg < M) __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(q.vb + off));
     } else {  // lane: row s0 + jj*16 + lr, columns d = pi*16 + 4*lg .. +3
       const uint32_t off = ((uint32_t)(jj * 16 + lr) * 64u + pi * 16 + 4 * lg) * 2u;
@@ -1452,13 +1453,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     //   read it: row d = it*16 + (ln >> 2), chunk ln & 3
     const int rd = ln >> 2, rc = ln & 3;
     const char* const gbase = patch + rd * 64 + ((rc ^ ((rd >> 2) & 3)) * 16);
-    const uint32_t voff0 = ((uint32_t)rd * (uint32_t)ep.S + rc * 8) * 2u;
+    const uint32_t voff0 = ((uint32_t)rd * 32u + rc * 8) * 2u;  // (the block is [64 d][64 B] in the bank too)
     uint4 pv;
     auto get = [&](int it) { return *reinterpret_cast<const uint4*>(gbase + it * 1024); };  // 16 rows = 1 KiB, swizzle term unchanged
     auto put = [&](int it, const uint4& v) {
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v),
-                                  reinterpret_cast<u32x4*>(q.vb + (voff0 + (uint32_t)(it * 16) * (uint32_t)ep.S * 2u)));
+                                  reinterpret_cast<u32x4*>(q.vb + (voff0 + (uint32_t)(it * 1024))));
     };
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -1717,7 +1718,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
               const int wsw = (lr >> 2) & 3, rd = ln >> 2, rc = ln & 3;
               char* const wbase = kvpatch + lr * 64 + (lg & 1) * 8;
               const char* const gbase = kvpatch + rd * 64 + ((rc ^ ((rd >> 2) & 3)) * 16);
-              const uint32_t voff0 = ((uint32_t)rd * (uint32_t)ep.S + rc * 8) * 2u;
+              const uint32_t voff0 = ((uint32_t)rd * 32u + rc * 8) * 2u;
               char* vb = q.vb;
               for (int pc = 0; pc < ep.split; ++pc) {
 #pragma unroll
@@ -1734,7 +1735,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
                   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                   const uint4 val = *reinterpret_cast<const uint4*>(gbase + it * 1024);
                   __builtin_nontemporal_store(__builtin_bit_cast(u32x4, val),
-                                              reinterpret_cast<u32x4*>(vb + (voff0 + (uint32_t)(it * 16) * (uint32_t)ep.S * 2u)));
+                                              reinterpret_cast<u32x4*>(vb + (voff0 + (uint32_t)(it * 1024))));
                 }
                 __builtin_amdgcn_wave_barrier();
                 vb += ep.bank_pstride * 2;
@@ -2087,7 +2088,7 @@ extern "C" int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M
     case GRAM_EPI_KV_BANK: {
       if (!bank || !bank->k || !bank->vt) return GRAM_E_ARG;
       const int inner = bank->H * 64;
-      if (inner % BN != 0 || N != bank->n_layers * 2 * inner || bank->S % 16 != 0) return GRAM_E_ARG;
+      if (inner % BN != 0 || N != bank->n_layers * 2 * inner || bank->S % 32 != 0) return GRAM_E_ARG;  // (V^T is blocked by 32 keys)
       if (bank->passage_map) {
         if (bank->L < 16 || bank->N < 1 || bank->N * bank->L != bank->S || M % bank->L != 0 || M > bank->B * bank->S) return GRAM_E_ARG;
       } else if (M != bank->B * bank->S) {

@@ -64,7 +64,7 @@ struct Workspace {
   float* rs;        // [Me]        1/rms per row
   // fused bank
   bf16* bank_k;     // [layers][B][H][S][64]
-  bf16* bank_vt;    // [layers][B][H][64][S]
+  bf16* bank_vt;    // [layers][B][H][S/32][64][32]
   // decoder
   float* xd;        // [R][d]
   bf16* hd;         // [R][d]

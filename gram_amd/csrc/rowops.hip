@@ -182,6 +182,51 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const uint4* __restric
   if ((a.x ^ a.y ^ a.z ^ a.w) == 0x9e3779b9u && sink) *sink = a.x;  // keeps the loads alive; practically never taken
 }
 
+// Variants of the probe (tests/bench_stream.py): V = 1 each workgroup sweeps contiguous 16-KiB chunks, 2 nontemporal loads,
+// 3 eight loads in flight per lane, 4 LDS-DMA (no registers), 5 = 1 with nontemporal loads
+template <int V>
+__global__ __launch_bounds__(256) void stream_read_var_kernel(const uint4* __restrict__ p, size_t n16, uint32_t* sink) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4* q = reinterpret_cast<const u32x4*>(p);
+  u32x4 a = {0, 0, 0, 0};
+  if constexpr (V == 1 || V == 5) {
+    const size_t nchunk = n16 / 1024;  // 16-KiB chunks
+    for (size_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+      const u32x4* b = q + c * 1024 + threadIdx.x;
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = V == 5 ? __builtin_nontemporal_load(b + 256 * u) : b[256 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a ^= v[u];
+    }
+  } else if constexpr (V == 2 || V == 3) {
+    constexpr int U = V == 3 ? 8 : 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+      u32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = V == 2 ? __builtin_nontemporal_load(q + i + u * stride) : q[i + u * stride];
+#pragma unroll
+      for (int u = 0; u < U; ++u) a ^= v[u];
+    }
+  } else {
+    __shared__ __attribute__((aligned(16))) char buf[4][8][1024];  // per wave: 8 DMA slots
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t nchunk = n16 / 2048;  // 32-KiB chunks: 8 KiB per wave
+    for (size_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+      const char* b = reinterpret_cast<const char*>(q + c * 2048 + wave * 512);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + u * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(&buf[wave][u][0]), 16, 0, 0);
+    }
+    __syncthreads();
+    a.x = *reinterpret_cast<const uint32_t*>(&buf[wave][0][lane * 4]);
+  }
+  if ((a.x ^ a.y ^ a.z ^ a.w) == 0x9e3779b9u && sink) *sink = a.x;
+}
+
 // passage cache -> residual stream: one 16-byte chunk per thread, consecutive threads on consecutive chunks of a row
 __global__ __launch_bounds__(256) void gather_passage_x_kernel(const float* __restrict__ cache, const int32_t* __restrict__ slot,
                                                                float* __restrict__ x, int64_t nchunks, int L, int cache_L, int d4) {
@@ -199,8 +244,29 @@ __global__ __launch_bounds__(256) void gather_passage_x_kernel(const float* __re
 
 extern "C" int gram_debug_stream_read(const void* src, size_t bytes, void* sink, void* stream) {
   if (!src || bytes < 16 || (reinterpret_cast<uintptr_t>(src) & 15)) return GRAM_E_ARG;
-  hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, bytes / 16,
-                     (uint32_t*)sink);
+  // the fastest access shape found (tests/bench_stream.py, profiles/r02j_stream_read_variants.jsonl): contiguous 16-KiB chunks per
+  // workgroup, nontemporal loads -- 7.0 TB/s where the grid-stride sweep of round 1 reads 5.7
+  if (bytes >= (1u << 20))
+    hipLaunchKernelGGL(stream_read_var_kernel<5>, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, bytes / 16, (uint32_t*)sink);
+  else
+    hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, bytes / 16, (uint32_t*)sink);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gram_debug_stream_read_variant(const void* src, size_t bytes, void* sink, int variant, int wgs, void* stream) {
+  if (!src || bytes < (1 << 20) || (reinterpret_cast<uintptr_t>(src) & 15) || wgs < 1) return GRAM_E_ARG;
+  const dim3 g(wgs), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(stream_read_kernel, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
+    case 1: hipLaunchKernelGGL(stream_read_var_kernel<1>, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
+    case 2: hipLaunchKernelGGL(stream_read_var_kernel<2>, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
+    case 3: hipLaunchKernelGGL(stream_read_var_kernel<3>, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
+    case 4: hipLaunchKernelGGL(stream_read_var_kernel<4>, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
+    case 5: hipLaunchKernelGGL(stream_read_var_kernel<5>, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
+    default: return GRAM_E_ARG;
+  }
   GRAM_CHECK_LAUNCH();
   return 0;
 }

@@ -115,8 +115,8 @@ def _(qkv, bias, mask, num_heads):
 # ---------------------------------------------------------------------------------------------- cross-attention decode
 @torch.library.custom_op("gram::cross_attn_decode", mutates_args=(), device_types="cuda")
 def cross_attn_decode(q: Tensor, k_bank: Tensor, vt_bank: Tensor, mask: Tensor, num_beams: int) -> Tensor:
-    """q bf16 (B*K, inner); k_bank bf16 (B, H, S, 64); vt_bank bf16 (B, H, 64, S) (one copy per user, shared by its K
-    beams); mask u8 (B, S) -> bf16 (B*K, inner)."""
+    """q bf16 (B*K, inner); k_bank bf16 (B, H, S, 64); vt_bank bf16 (B, H, S/32, 64, 32) = V transposed, blocked by 32 keys (one
+    copy per user, shared by its K beams); mask u8 (B, S) -> bf16 (B*K, inner)."""
     B, H, S, _ = k_bank.shape
     out = torch.empty_like(q)
     with torch.cuda.device(q.device):

@@ -47,7 +47,8 @@ enum gram_epilogue {
 
 /* Fused cross-attention KV bank for B users, S = N*L fused tokens, n_layers decoder layers:
  *   k  : [layer][b][h][s][64]   bf16   (key rows contiguous: streamed 128 B per key)
- *   vt : [layer][b][h][64][s]   bf16   (V transposed: the MFMA A operand is read k-contiguous)
+ *   vt : [layer][b][h][s/32][64][32] bf16 (V transposed and blocked by 32 keys: the 64 x 32 tile of a 32-key step is 4 KiB
+ *                                    contiguous, fetched as whole 128-B lines like a K tile; S % 32 == 0)
  * Beam-invariant: ONE copy per user, shared by the user's K beams (the reference replicates it
  * K times and index_select-s it every step: gram_t5_modeling.py:531-549, gram_t5.py:320-348). */
 typedef struct {
@@ -435,6 +436,9 @@ int gram_debug_set_gemm_variant(int variant);
 /* Calibration probe (bench.py): one streaming read of `bytes` (16-B aligned) through every CU; nothing is
  * written unless a 32-bit fold of the data hits one magic value (sink may be NULL). */
 int gram_debug_stream_read(const void* src, size_t bytes, void* sink, void* stream);
+/* variants of the probe (tests/bench_stream.py): 0 = gram_debug_stream_read's kernel, 1 contiguous 16-KiB chunks per workgroup, 2 nontemporal,
+ * 3 eight loads in flight, 4 LDS-DMA, 5 = 1 + nontemporal; wgs = workgroups of 256 threads */
+int gram_debug_stream_read_variant(const void* src, size_t bytes, void* sink, int variant, int wgs, void* stream);
 
 /* A/B hook (bench.py): 0 = decode every row in every step like the reference, 1 = live-row compaction (gram_live_rows_t),
  * -1 = what the GRAM_LIVE_ROWS environment variable says (default 1).  Results are bit-identical either way. */

@@ -47,11 +47,11 @@ if __name__ == "__main__":
         us, gbs = one(pieces, B=B, H=H, S=S, K=K)
         print(json.dumps({"pieces": pieces, "B": B, "H": H, "S": S, "K": K, "us": round(us, 1), "GBps": round(gbs, 1)}))
     elif len(sys.argv) > 1:
-        for ub in (True, False, True, False):
+        for ub in (True, True):
             us, gbs = one(int(sys.argv[1]), use_bits=ub)
             print(json.dumps({"variant": os.environ.get("GRAM_XA_VARIANT", "default"), "pieces": int(sys.argv[1]), "key_bits": ub, "us": round(us, 1), "GBps": round(gbs, 1)}))
     else:
-        for pieces, variants in ((1, ["", "21", "22", "13"]), (2, ["", "21", "22", "11"])):
+        for pieces, variants in ((1, ["", "21", "22", "12", "13", "41", "42"]), (2, ["", "21", "22", "11", "12", "41"])):
             for v in variants:
                 env = dict(os.environ)
                 if v:

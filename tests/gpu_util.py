@@ -71,3 +71,15 @@ def device_beam_search(logits_per_step, flat_trie, B, K, max_length, lp=1.0, nre
     torch.cuda.synchronize()
     w = int(width[0])
     return seqs[:, :w].cpu(), scores.cpu(), int(keep["error"][0]), trace
+
+
+def vt_blocked(vt):
+    """[..., 64, S] (V transposed) -> the bank's layout [..., S/32, 64, 32]: V^T blocked by 32 keys, so that the 64 x 32 tile of a
+    32-key step is 4 KiB contiguous (include/gram_hip.h, gram_kv_bank_t)."""
+    S = vt.shape[-1]
+    return vt.unflatten(-1, (S // 32, 32)).transpose(-3, -2).contiguous()
+
+
+def vt_unblocked(vtb):
+    """inverse of vt_blocked: [..., S/32, 64, 32] -> [..., 64, S]"""
+    return vtb.transpose(-3, -2).flatten(-2)

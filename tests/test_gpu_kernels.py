@@ -215,12 +215,12 @@ def test_gemm_kv_bank(G):
     A = G.bf(_r(B * S, d, seed=4))
     W = G.bf(_r(layers * 2 * inner, d, seed=5, scale=d ** -0.5))
     k = torch.zeros(layers, B, H, S, 64, dtype=torch.bfloat16, device=G.DEV)
-    vt = torch.zeros(layers, B, H, 64, S, dtype=torch.bfloat16, device=G.DEV)
+    vt = torch.zeros(layers, B, H, S // 32, 64, 32, dtype=torch.bfloat16, device=G.DEV)  # V^T blocked by 32 keys
     bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, B, H, S)
     G.gemm(A, W, _lib.EPI_KV_BANK, None, bank)
     ref = (A.float() @ W.float().T).view(B, S, layers, 2, H, 64)
     assert torch.allclose(k.float(), ref[:, :, :, 0].permute(2, 0, 3, 1, 4), atol=2e-2, rtol=1e-2)
-    assert torch.allclose(vt.float(), ref[:, :, :, 1].permute(2, 0, 3, 4, 1), atol=2e-2, rtol=1e-2)
+    assert torch.allclose(G.vt_unblocked(vt).float(), ref[:, :, :, 1].permute(2, 0, 3, 4, 1), atol=2e-2, rtol=1e-2)
 
 
 @pytest.mark.parametrize("compact", [False, True])
@@ -255,7 +255,7 @@ def test_gemm_kv_bank_persistent(G, compact):
         for v in (3, 22):
             L_.gram_debug_set_gemm_variant(v)
             k = torch.zeros(layers, B, H, S, 64, dtype=torch.bfloat16, device=G.DEV)
-            vt = torch.zeros(layers, B, H, 64, S, dtype=torch.bfloat16, device=G.DEV)
+            vt = torch.zeros(layers, B, H, S // 32, 64, 32, dtype=torch.bfloat16, device=G.DEV)
             if compact:
                 pm = pmap.to(G.DEV)
                 bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, B, H, S, pm.data_ptr(), pN, pL)
@@ -275,7 +275,7 @@ def test_gemm_kv_bank_persistent(G, compact):
         b_idx, s_idx = rows // S, rows % S
     for v, (k, vt) in res.items():
         kk = k.float()[:, b_idx, :, s_idx]        # advanced indices split by a slice: result is [M, layers, H, 64]
-        vv = vt.float()[:, b_idx, :, :, s_idx]    # [M, layers, H, 64]
+        vv = G.vt_unblocked(vt).float()[:, b_idx, :, :, s_idx]    # [M, layers, H, 64]
         assert torch.allclose(kk, ref[:, :, 0], atol=2e-2, rtol=1e-2), v
         assert torch.allclose(vv, ref[:, :, 1], atol=2e-2, rtol=1e-2), v
     assert torch.equal(res[3][0], res[22][0]) and torch.equal(res[3][1], res[22][1])
@@ -356,7 +356,7 @@ def test_cross_attn_decode(G, K, S):
     q = G.bf(torch.randn(B * K, inner, generator=g) * 0.3)
     kb = G.bf(torch.randn(B, H, S, 64, generator=g))
     vb = torch.randn(B, H, S, 64, generator=g)
-    vt = G.bf(vb.transpose(2, 3).contiguous())
+    vt = G.bf(G.vt_blocked(vb.transpose(2, 3).contiguous()))
     mask = torch.rand(B, S, generator=g) > 0.3
     mask[1, : S // 2] = False  # leading masked steps (whole 32-key steps of -min before any valid key)
     if S >= 64:
@@ -366,7 +366,7 @@ def test_cross_attn_decode(G, K, S):
     _lib.check(G.lib().gram_cross_attn_decode(G.p(q), G.p(kb), G.p(vt), G.p(m8), G.p(out), B, K, H, S, G.stream()), "xattn")
     qh = q.float().cpu().view(B, K, H, 64).permute(0, 2, 1, 3)  # (B,H,K,64)
     ext = ((1.0 - mask.float()) * O.FMIN)[:, None, None, :]
-    ref = O._attend(qh, kb.float().cpu(), vt.float().cpu().transpose(2, 3), ext).reshape(B * K, inner)
+    ref = O._attend(qh, kb.float().cpu(), G.vt_unblocked(vt).float().cpu().transpose(2, 3), ext).reshape(B * K, inner)
     # bf16 P and bf16 output on O(1) values: 1e-2 abs (observed max ~6e-3)
     assert torch.allclose(out.float().cpu(), ref, atol=1e-2, rtol=1e-2)
 
@@ -379,11 +379,11 @@ def test_cross_attn_all_masked_user(G):
     q = G.bf(torch.randn(B * K, 64, generator=g))
     kb = G.bf(torch.randn(B, H, S, 64, generator=g))
     vb = torch.randn(B, H, S, 64, generator=g)
-    vt = G.bf(vb.transpose(2, 3).contiguous())
+    vt = G.bf(G.vt_blocked(vb.transpose(2, 3).contiguous()))
     m8 = torch.zeros(B, S, dtype=torch.uint8, device=G.DEV)
     out = torch.empty(B * K, 64, dtype=torch.bfloat16, device=G.DEV)
     _lib.check(G.lib().gram_cross_attn_decode(G.p(q), G.p(kb), G.p(vt), G.p(m8), G.p(out), B, K, H, S, G.stream()), "xattn")
-    ref = vt.float().cpu()[0, 0].mean(-1)  # uniform average over keys
+    ref = G.vt_unblocked(vt).float().cpu()[0, 0].mean(-1)  # uniform average over keys
     assert torch.allclose(out.float().cpu(), ref.expand(K, 64), atol=2e-2, rtol=2e-2)
 
 

@@ -97,7 +97,7 @@ def test_split_gemm_kv_bank(G, pieces):
     A, W = pieces_of(a32, pieces), expand_w(w32, pieces)
     ref = (a32.double() @ w32.double().T).view(B, S, layers, 2, H, 64)
     k = torch.zeros(pieces, layers, B, H, S, 64, dtype=torch.bfloat16, device=G.DEV)
-    vt = torch.zeros(pieces, layers, B, H, 64, S, dtype=torch.bfloat16, device=G.DEV)
+    vt = torch.zeros(pieces, layers, B, H, S // 32, 64, 32, dtype=torch.bfloat16, device=G.DEV)  # V^T blocked by 32 keys
     bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, B, H, S)
     sp = _lib.Split(pieces, M * d, 0, 0, k[0].numel())
     _lib.check(L_.gram_gemm_bf16_split(G.p(A), G.p(W), None, M, layers * 2 * inner, d, d, 0, _lib.EPI_KV_BANK, C.byref(bank), None,
@@ -106,7 +106,7 @@ def test_split_gemm_kv_bank(G, pieces):
     kref = ref[:, :, :, 0].permute(2, 0, 3, 1, 4)   # (layers,B,H,S,64)
     vref = ref[:, :, :, 1].permute(2, 0, 3, 4, 1)   # (layers,B,H,64,S)
     assert relerr(join(k), kref) < TOL[pieces]
-    assert relerr(join(vt), vref) < TOL[pieces]
+    assert relerr(join(G.vt_unblocked(vt)), vref) < TOL[pieces]
 
 
 @pytest.mark.parametrize("pieces", [2, 3])
@@ -150,7 +150,7 @@ def test_split_cross_attn(G, pieces, K, S):
     q32 = (torch.randn(B * K, inner, generator=g) * 0.3).to(G.DEV)
     k32 = torch.randn(B, H, S, 64, generator=g).to(G.DEV)
     v32 = torch.randn(B, H, S, 64, generator=g).to(G.DEV)
-    q, kb, vt = pieces_of(q32, pieces), pieces_of(k32, pieces), pieces_of(v32.transpose(2, 3).contiguous(), pieces)
+    q, kb, vt = pieces_of(q32, pieces), pieces_of(k32, pieces), pieces_of(G.vt_blocked(v32.transpose(2, 3).contiguous()), pieces)
     mask = torch.rand(B, S, generator=g) > 0.3
     mask[1, : S // 2] = False
     if S >= 64:
@@ -343,7 +343,7 @@ def test_split_gemm_kv_bank_persistent(G, pieces, compact):
         for v in (3, 22):
             L_.gram_debug_set_gemm_variant(v)
             k = torch.zeros(pieces, layers, B, H, S, 64, dtype=torch.bfloat16, device=G.DEV)
-            vt = torch.zeros(pieces, layers, B, H, 64, S, dtype=torch.bfloat16, device=G.DEV)
+            vt = torch.zeros(pieces, layers, B, H, S // 32, 64, 32, dtype=torch.bfloat16, device=G.DEV)
             pm = pmap.to(G.DEV) if compact else None
             bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, B, H, S, pm.data_ptr() if compact else None, pN, pL)
             sp = _lib.Split(pieces, M * d, 0, 0, k[0].numel())

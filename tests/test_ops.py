@@ -17,7 +17,7 @@ def test_ops_are_registered_with_fake_impls():
         assert torch.ops.gram.linear(a, w).shape == (20, 2304)
         q = torch.empty(40, 768, dtype=torch.bfloat16, device="cuda")
         kb = torch.empty(2, 12, 384, 64, dtype=torch.bfloat16, device="cuda")
-        vt = torch.empty(2, 12, 64, 384, dtype=torch.bfloat16, device="cuda")
+        vt = torch.empty(2, 12, 384 // 32, 64, 32, dtype=torch.bfloat16, device="cuda")
         mk = torch.empty(2, 384, dtype=torch.uint8, device="cuda")
         assert torch.ops.gram.cross_attn_decode(q, kb, vt, mk, 20).shape == (40, 768)
         ids = torch.empty(3, 2, 32, dtype=torch.int64, device="cuda")
@@ -48,10 +48,11 @@ def test_ops_values_on_gpu():
     B, H, K, S = 2, 2, 5, 96
     q = (torch.randn(B * K, H * 64, generator=g) * 0.3).to(torch.bfloat16).cuda()
     kb = torch.randn(B, H, S, 64, generator=g).to(torch.bfloat16).cuda()
-    vt = torch.randn(B, H, 64, S, generator=g).to(torch.bfloat16).cuda()
+    v_t = torch.randn(B, H, 64, S, generator=g).to(torch.bfloat16)
+    vt = v_t.unflatten(-1, (S // 32, 32)).transpose(-3, -2).contiguous().cuda()  # the bank's V^T, blocked by 32 keys
     mask = torch.rand(B, S, generator=g) > 0.3
     out = torch.ops.gram.cross_attn_decode(q, kb, vt, mask.cuda().view(torch.uint8).contiguous(), K)
     qh = q.float().cpu().view(B, K, H, 64).permute(0, 2, 1, 3)
     ext = ((1.0 - mask.float()) * O.FMIN)[:, None, None, :]
-    ref = O._attend(qh, kb.float().cpu(), vt.float().cpu().transpose(2, 3), ext).reshape(B * K, H * 64)
+    ref = O._attend(qh, kb.float().cpu(), v_t.float().transpose(2, 3), ext).reshape(B * K, H * 64)
     assert torch.allclose(out.float().cpu(), ref, atol=1e-2, rtol=1e-2)
