@@ -39,7 +39,7 @@ __device__ __forceinline__ void dma16_nt(uint32_t lds_addr /*wave-uniform*/, uin
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
 }
 #ifndef GRAM_XA_NT
-#define GRAM_XA_NT 3  // bit 0 = K tiles, bit 1 = V^T tiles fetched with the nt hint (A/B build hook; measured 5.55 -> 6.04 TB/s at the bench shape)
+#define GRAM_XA_NT 1  // bit 0 = K tiles, bit 1 = V^T tiles fetched with the nt hint (A/B build hook; in the bench, one box: 168.8 ms of cross-attention per step without, 163.3 with K only, 165.7 with both)
 #endif
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -169,11 +169,12 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     }
   };
   const int krow = 8 * (c >> 2) + (c & 3);  // + 4t: key row of S^T tile t this lane feeds
-  auto compute = [&](int slot, int step) {
+  // A stage is consumed in two phases: read_frags pulls every K and V^T fragment of the step out of the ring slot into registers, and
+  // once those reads have returned the slot is re-filled (the next step's DMAs are in flight during the whole of `math`, which
+  // works on registers only) -- with one stage per wave and the issue after the math, a wave had nothing in flight while it computed.
+  bf16x8 kf[S][2][2], vf[S][4];
+  auto read_frags = [&](int slot) {
     const char* stg = smem + wave * RING + slot * STAGE;
-    const uint32_t kword = step < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)kb0, step) : (uint32_t)__builtin_amdgcn_readlane((int)kb1, step - 64);
-    const uint32_t kbits = kword >> (8 * g);  // this lane's keys 8g + 4t + j
-    bf16x8 kf[S][2][2], vf[S][4];
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) {
 #pragma unroll
@@ -189,6 +190,10 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
         vf[pc][mt] = *reinterpret_cast<const bf16x8*>(stg + pc * 2 * XA_TILE + XA_TILE + d * 64 + ((g ^ vsw(d)) << 4));
       }
     }
+  };
+  auto math = [&](int step) {
+    const uint32_t kword = step < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)kb0, step) : (uint32_t)__builtin_amdgcn_readlane((int)kb1, step - 64);
+    const uint32_t kbits = kword >> (8 * g);  // this lane's keys 8g + 4t + j
     bf16x8 pf[S][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -288,16 +293,17 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
       int cur = rq[0];
 #pragma unroll
       for (int i = 1; i < R; ++i) cur = head == i ? rq[i] : cur;
-      compute(head, cur);
+      read_frags(head);
       --inflight;
       if (last < nsteps) last = next(last);
       if (last < nsteps) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this slot's fragment reads are done before it is re-filled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this slot's fragment reads have returned before it is re-filled
         issue(head, last);
 #pragma unroll
         for (int i = 0; i < R; ++i) rq[i] = head == i ? last : rq[i];
         ++inflight;
       }
+      math(cur);
       head = head + 1 == R ? 0 : head + 1;
     }
   }
@@ -540,8 +546,8 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restri
       for (int e = 0; e < 4; ++e) kj[e] = vj[e] = 0.f;
 #pragma unroll
       for (int pc = S - 1; pc >= 0; --pc) {
-        const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(kcache + pc * cache_ps + ((size_t)j * R + a) * inner + 4 * i);
-        const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(vcache + pc * cache_ps + ((size_t)j * R + a) * inner + 4 * i);
+        const bf16x4 k4 = ld_stream_b64(kcache + pc * cache_ps + ((size_t)j * R + a) * inner + 4 * i);
+        const bf16x4 v4 = ld_stream_b64(vcache + pc * cache_ps + ((size_t)j * R + a) * inner + 4 * i);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           kj[e] += (float)k4[e];

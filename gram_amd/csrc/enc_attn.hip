@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
     for (int it = 0; it < NKS; ++it) {
       const int i = tid + it * 256, row = i >> 3, c = i & 7;
       const bf16* src = base + pc * qkv_pstride + (size_t)row * rs + c * 8;
-      kv[it] = ld_global_b128(src + inner);
-      vv[it] = ld_global_b128(src + 2 * inner);
+      kv[it] = ld_stream_b128(src + inner);
+      vv[it] = ld_stream_b128(src + 2 * inner);
     }
 #pragma unroll
     for (int it = 0; it < NKS; ++it) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int kd = 0; kd < 2; ++kd)
-        qf[pc][nt][kd] = ld_global_b128(base + pc * qkv_pstride + (size_t)(q0 + 16 * nt + c) * rs + 32 * kd + 8 * g);
+        qf[pc][nt][kd] = ld_stream_b128(base + pc * qkv_pstride + (size_t)(q0 + 16 * nt + c) * rs + 32 * kd + 8 * g);
 
   f32x4 s[NKS][2][2];
 #pragma unroll

@@ -11,15 +11,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def one(pieces, B=4096, H=12, S=384, K=20, reps=20, use_bits=True):
+def one(pieces, B=4096, H=12, S=384, K=20, reps=20, use_bits=True, layers=1):
     import torch
     from gram_amd import _lib
     lib = _lib.load()
     dev = "cuda:0"
     inner = H * 64
     q = torch.randn(pieces, B * K, inner, device=dev).to(torch.bfloat16)
-    kb = torch.randn(pieces, B, H, S, 64, device=dev).to(torch.bfloat16)
-    vt = torch.randn(pieces, B, H, 64, S, device=dev).to(torch.bfloat16)
+    # layers > 1: every launch reads another layer's slice of a [pieces][layers] bank, as a decode step does (the whole bank is
+    # 12 x 9.7 GB at the bench shape: no launch finds its pages where the previous one left the TLBs)
+    kbs = torch.randn(pieces, layers, B, H, S, 64, device=dev, dtype=torch.bfloat16)
+    vts = torch.randn(pieces, layers, B, H, S // 32, 64, 32, device=dev, dtype=torch.bfloat16)
+    kb, vt = kbs[:, 0], vts[:, 0]
+    pstride = kbs[0].numel()
+    lstride = kbs[0, 0].numel() * 2  # bytes
+    it = [0]
     mask = torch.ones(B, S, dtype=torch.uint8, device=dev)
     out = torch.empty(pieces, B * K, inner, dtype=torch.bfloat16, device=dev)
     st = torch.cuda.current_stream().cuda_stream
@@ -27,8 +33,10 @@ def one(pieces, B=4096, H=12, S=384, K=20, reps=20, use_bits=True):
     _lib.check(lib.gram_mask_key_bits(mask.data_ptr(), bits.data_ptr(), B, S, st), "bits")
 
     def run():
-        _lib.check(lib.gram_cross_attn_decode_split(q.data_ptr(), kb.data_ptr(), vt.data_ptr(), mask.data_ptr(), out.data_ptr(), B, K, H, S,
-                                                    None, None, pieces, q[0].numel(), kb[0].numel(), out[0].numel(), bits.data_ptr() if use_bits else None, st), "xattn")
+        ly = it[0] % layers
+        it[0] += 1
+        _lib.check(lib.gram_cross_attn_decode_split(q.data_ptr(), kbs.data_ptr() + ly * lstride, vts.data_ptr() + ly * lstride, mask.data_ptr(), out.data_ptr(), B, K, H, S,
+                                                    None, None, pieces, q[0].numel(), pstride, out[0].numel(), bits.data_ptr() if use_bits else None, st), "xattn")
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,8 +52,9 @@ def one(pieces, B=4096, H=12, S=384, K=20, reps=20, use_bits=True):
 if __name__ == "__main__":
     if len(sys.argv) > 2:  # pieces B H S K: one shape, e.g. config 5's  `2 512 16 2688 50`
         pieces, B, H, S, K = (int(x) for x in sys.argv[1:6])
-        us, gbs = one(pieces, B=B, H=H, S=S, K=K)
-        print(json.dumps({"pieces": pieces, "B": B, "H": H, "S": S, "K": K, "us": round(us, 1), "GBps": round(gbs, 1)}))
+        layers = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+        us, gbs = one(pieces, B=B, H=H, S=S, K=K, layers=layers, reps=max(20, 2 * layers))
+        print(json.dumps({"pieces": pieces, "B": B, "H": H, "S": S, "K": K, "layers": layers, "us": round(us, 1), "GBps": round(gbs, 1)}))
     elif len(sys.argv) > 1:
         for ub in (True, True):
             us, gbs = one(int(sys.argv[1]), use_bits=ub)
