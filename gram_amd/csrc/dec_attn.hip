@@ -92,6 +92,23 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     for (int mt = 0; mt < 4; ++mt) o[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
+  if constexpr (R == 1) {
+    // query fragments: requested first, in parallel with the key bits, and retired with them by the wait in front of the ring --
+    // the counted waits of the half-stage loop must see DMA instructions only
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int beam = 16 * nt + c;
+      int qrow = beam < K ? b * K + beam : -1;
+      if constexpr (LIVE) {
+        if (qrow >= 0) qrow = rowpos[qrow];
+      }
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc)
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd)
+          qf[pc][nt][kd] = qrow >= 0 ? ld_global_b128(q + pc * q_pstride + (size_t)qrow * inner + h * 64 + 32 * kd + 8 * g) : zero_bf16x8();
+    }
+  }
   // Fully masked 32-key steps (padded passages / padded tails) are never fetched: the algorithmic
   // traffic is proportional to the VALID fused keys.  One word of key bits per step (S <= 4096 -> <= 128 steps);
   // the valid steps are dealt round-robin to the waves.  A user with no valid key at all keeps
@@ -150,17 +167,24 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     voff[i] = (uint32_t)(d * 64 + (((lane & 3) ^ vsw(d)) << 4));  // (the bank's V^T is blocked by 32 keys: a step's tile is [64 d][64 B], contiguous)
   }
   const uint32_t ring0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * RING;
-  auto issue = [&](int slot, int step) {  // 8 * S DMA instructions: this step's K and V^T tiles of every piece -> ring slot
+  // 4 * S DMA instructions each: this step's K tiles / V^T tiles of every piece -> ring slot
+  auto issue_k = [&](int slot, int step) {
     const uint32_t dst = ring0 + slot * STAGE;
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) {
       const char* kbase = kb + (size_t)pc * bank_pstride * 2 + (size_t)step * (32 * 128);
-      const char* vbase = vt + (size_t)pc * bank_pstride * 2 + (size_t)step * 4096;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if constexpr ((GRAM_XA_NT & 1) != 0) dma16_nt(dst + pc * 2 * XA_TILE + i * 1024, koff[i], kbase);
         else dma16(dst + pc * 2 * XA_TILE + i * 1024, koff[i], kbase);
       }
+    }
+  };
+  auto issue_v = [&](int slot, int step) {
+    const uint32_t dst = ring0 + slot * STAGE;
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc) {
+      const char* vbase = vt + (size_t)pc * bank_pstride * 2 + (size_t)step * 4096;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if constexpr ((GRAM_XA_NT & 2) != 0) dma16_nt(dst + pc * 2 * XA_TILE + XA_TILE + i * 1024, voff[i], vbase);
@@ -168,15 +192,19 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
       }
     }
   };
+  auto issue = [&](int slot, int step) {
+    issue_k(slot, step);
+    issue_v(slot, step);
+  };
   const int krow = 8 * (c >> 2) + (c & 3);  // + 4t: key row of S^T tile t this lane feeds
   // A stage is consumed in two phases: read_frags pulls every K and V^T fragment of the step out of the ring slot into registers, and
   // once those reads have returned the slot is re-filled (the next step's DMAs are in flight during the whole of `math`, which
   // works on registers only) -- with one stage per wave and the issue after the math, a wave had nothing in flight while it computed.
   bf16x8 kf[S][2][2], vf[S][4];
-  auto read_frags = [&](int slot) {
+  auto read_k = [&](int slot) {
     const char* stg = smem + wave * RING + slot * STAGE;
 #pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
+    for (int pc = 0; pc < S; ++pc)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -184,17 +212,25 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
           const int r = krow + 4 * t;
           kf[pc][t][kd] = *reinterpret_cast<const bf16x8*>(stg + pc * 2 * XA_TILE + r * 128 + (((g + 4 * kd) ^ ksw(r)) << 4));
         }
+  };
+  auto read_v = [&](int slot) {
+    const char* stg = smem + wave * RING + slot * STAGE;
+#pragma unroll
+    for (int pc = 0; pc < S; ++pc)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int d = 16 * mt + c;
         vf[pc][mt] = *reinterpret_cast<const bf16x8*>(stg + pc * 2 * XA_TILE + XA_TILE + d * 64 + ((g ^ vsw(d)) << 4));
       }
-    }
   };
-  auto math = [&](int step) {
+  auto read_frags = [&](int slot) {
+    read_k(slot);
+    read_v(slot);
+  };
+  bf16x8 pf[S][NT];  // exp(S^T - max) of the step, as pieces: the B operand of O^T += V^T P^T
+  auto math_qk = [&](int step) {
     const uint32_t kword = step < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)kb0, step) : (uint32_t)__builtin_amdgcn_readlane((int)kb1, step - 64);
     const uint32_t kbits = kword >> (8 * g);  // this lane's keys 8g + 4t + j
-    bf16x8 pf[S][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       f32x4 s[2];
@@ -239,6 +275,8 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) o[mt][nt] *= alpha;
     }
+  };
+  auto math_pv = [&]() {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -246,12 +284,54 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
 #pragma unroll
         for (int pr = 0; pr < T::NP; ++pr) o[mt][nt] = mfma16(vf[T::A[pr]][mt], pf[T::B[pr]][nt], o[mt][nt]);
   };
+  auto math = [&](int step) {
+    math_qk(step);
+    math_pv();
+  };
 
   // Everything the first DMAs depend on (the key bits) is in; ordinary loads are retired so that the counted waits below see
   // DMA instructions only.  The query fragments are loaded AFTER the ring is primed: their latency hides behind the first stages
   // (hipcc waits for them with vmcnt(0) at their first use, which the first stage has to reach anyway).
   wait_vm<0>();
-  {
+  if constexpr (R == 1) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc)
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd) asm volatile("" : "+v"(qf[pc][nt][kd]));  // (hipcc's own wait for the loads goes HERE)
+    // One stage per wave, consumed and re-filled in HALVES: the K tiles of step s+1 are requested as soon as the K fragments of step
+    // s are in registers (and fly during S^T, softmax), its V^T tiles as soon as the V^T fragments of step s are (and fly during
+    // O^T += V^T P^T and the next S^T): the wave always has a half-stage in flight, where waiting for the whole stage and
+    // re-filling it after the reads left nothing in flight for a few hundred cycles of every step.
+    int cur = next(-1);
+    if (cur < nsteps) issue(0, cur);
+    while (cur < nsteps) {
+      const int nxt = next(cur);
+      wait_vm<4 * S>();  // all but the newest half-stage (this step's V^T tiles): its K tiles have landed
+      read_k(0);
+      if (nxt < nsteps) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the K fragments are in registers before their tiles are re-filled
+        issue_k(0, nxt);
+      }
+#ifndef GRAM_XA_NOMATH
+      math_qk(cur);
+#endif
+      if (nxt < nsteps) wait_vm<4 * S>();  // (newest: the next step's K tiles)
+      else wait_vm<0>();
+      read_v(0);
+      if (nxt < nsteps) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_v(0, nxt);
+      }
+#ifndef GRAM_XA_NOMATH
+      math_pv();
+#else
+      o[0][0][0] += (float)kf[0][0][0][0] + (float)vf[0][0][0];
+#endif
+      cur = nxt;
+    }
+  } else {
     // ring of R stages: rq[i] = step held by slot i; `head` is the oldest.  All scalar state.
     int rq[R];
     int head = 0, inflight = 0, last = -1;
@@ -303,7 +383,11 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
         for (int i = 0; i < R; ++i) rq[i] = head == i ? last : rq[i];
         ++inflight;
       }
+#ifndef GRAM_XA_NOMATH
       math(cur);
+#else
+      o[0][0][0] += (float)kf[0][0][0][0] + (float)vf[0][0][0];  // (probe build: the stream without the arithmetic)
+#endif
       head = head + 1 == R ? 0 : head + 1;
     }
   }

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void stream_read_var_kernel(const uint4* __res
 #pragma unroll
       for (int u = 0; u < U; ++u) a ^= v[u];
     }
-  } else {
+  } else if constexpr (V == 4) {
     __shared__ __attribute__((aligned(16))) char buf[4][8][1024];  // per wave: 8 DMA slots
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t nchunk = n16 / 2048;  // 32-KiB chunks: 8 KiB per wave
@@ -223,6 +223,27 @@ __global__ __launch_bounds__(256) void stream_read_var_kernel(const uint4* __res
     }
     __syncthreads();
     a.x = *reinterpret_cast<const uint32_t*>(&buf[wave][0][lane * 4]);
+  }
+  if constexpr (V == 6 || V == 7) {  // LDS-DMA through inline asm, with the nt hint (6) / without (7); 16 KiB per wave in flight, counted waits
+    __shared__ __attribute__((aligned(16))) char buf2[4][2][8][1024];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&buf2[wave][0][0][0];
+    const size_t nchunk = n16 / 2048;
+    int par = 0;
+    for (size_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+      const char* b = reinterpret_cast<const char*>(q + c * 2048 + wave * 512);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if constexpr (V == 6)
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds0 + par * 8192 + u * 1024), "v"((uint32_t)(lane * 16)), "s"(b + u * 1024) : "memory");
+        else
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + par * 8192 + u * 1024), "v"((uint32_t)(lane * 16)), "s"(b + u * 1024) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the previous chunk has landed
+      par ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    a.x = *reinterpret_cast<const uint32_t*>(&buf2[wave][0][0][lane * 4]);
   }
   if ((a.x ^ a.y ^ a.z ^ a.w) == 0x9e3779b9u && sink) *sink = a.x;
 }
@@ -265,6 +286,8 @@ extern "C" int gram_debug_stream_read_variant(const void* src, size_t bytes, voi
     case 3: hipLaunchKernelGGL(stream_read_var_kernel<3>, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
     case 4: hipLaunchKernelGGL(stream_read_var_kernel<4>, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
     case 5: hipLaunchKernelGGL(stream_read_var_kernel<5>, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
+    case 6: hipLaunchKernelGGL(stream_read_var_kernel<6>, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
+    case 7: hipLaunchKernelGGL(stream_read_var_kernel<7>, g, b, 0, st, (const uint4*)src, bytes / 16, (uint32_t*)sink); break;
     default: return GRAM_E_ARG;
   }
   GRAM_CHECK_LAUNCH();

@@ -39,6 +39,25 @@ def one(pieces, B=4096, H=12, S=384, K=20, reps=20, use_bits=True, layers=1):
                                                     None, None, pieces, q[0].numel(), pstride, out[0].numel(), bits.data_ptr() if use_bits else None, st), "xattn")
     for _ in range(3):
         run()
+    if os.environ.get("XA_HEAT"):
+        # every timed launch right behind a large GEMM, as in a decode step (does the kernel see the clocks / power state the GEMMs
+        # leave behind?): per-launch events, the GEMMs are not in the sum
+        M, N_, K_ = 81920, 2304, 768
+        ga = torch.randn(M, K_, device=dev).to(torch.bfloat16)
+        gw = torch.randn(N_, K_, device=dev).to(torch.bfloat16)
+        gc = torch.empty(M, N_, dtype=torch.bfloat16, device=dev)
+        ev = []
+        for _ in range(reps):
+            for _ in range(int(os.environ["XA_HEAT"])):
+                _lib.check(lib.gram_gemm_bf16(ga.data_ptr(), gw.data_ptr(), gc.data_ptr(), M, N_, K_, K_, N_, _lib.EPI_BF16, None, st), "gemm")
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            run()
+            b_.record()
+            ev.append((a, b_))
+        torch.cuda.synchronize()
+        us = sum(a.elapsed_time(b_) for a, b_ in ev) * 1e3 / reps
+        return us, 4.0 * B * H * S * 64 * pieces / (us * 1e-6) / 1e9
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
