@@ -554,6 +554,7 @@ int launch_cross_v(const void* q, const void* k, const void* vt, const uint8_t* 
   // (1, 2) 5.11 / 5.21, (2, 2) 5.21 / 4.84, (4, 2) 4.49 / 3.88 on the same box)
   // (three or four beam tiles, K > 32: the per-workgroup state is larger and one wave per (user, head) with two stages wins --
   // K = 50, S = 2 688, H = 16: (1, 2) 4.32 / 5.28 TB/s against (2, 1) 3.93 / 4.99, (2, 2) 4.08 / 4.95, (4, 1) 3.66 / 4.75)
+  // (a ring of 3 stages per wave for grids of a handful of users was measured too: 12.42 -> 12.67 ms per one-user generate, no gain)
   if constexpr (NT >= 3) return launch_cross<NT, S, 1, 2>(XA_ARGS);
   else return launch_cross<NT, S, 2, 1>(XA_ARGS);
 #undef XA_ARGS

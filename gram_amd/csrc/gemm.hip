@@ -40,6 +40,9 @@
 
 namespace {
 
+#ifndef GRAM_PP_RES_NT
+#define GRAM_PP_RES_NT 0  // A/B build hook: the ping-pong kernel's residual read with the nt hint
+#endif
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 
@@ -1072,7 +1075,11 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int mr = min(half * 64 + q * 4 + (lane >> 4), o.rows - 1);  // rows past M inside the block: clamped, never stored
+#if GRAM_PP_RES_NT
+          res[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(o.c + ((uint32_t)mr * o.ldc_b + (lane & 15) * 16)));
+#else
           res[q] = *reinterpret_cast<const f32x4*>(o.c + ((uint32_t)mr * o.ldc_b + (lane & 15) * 16));
+#endif
         }
       }
     }
