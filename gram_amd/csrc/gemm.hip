@@ -1848,7 +1848,10 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     }
     // tile order (see decode() in the kernel): m-grouped where there are enough n-tiles for it to shrink an XCD's panel set
     // measured (same box, whole path): n-fastest 6 684, groups of 4: 6 752, 6: 6 774, 8: 6 762 users/s
-    static const int gm_env = getenv("GRAM_GEMM_GROUPM") ? atoi(getenv("GRAM_GEMM_GROUPM")) : 6;  // A/B hook (0/1: n fastest)
+    // split operands (K' = 3K / 6K: panels three / six times the size), same box, GEMM ms per step: groups of 2: 1 097, 3: 1 100, 4: 1 088,
+    // 5: 1 098, 6: 1 097, 8: 1 091, 12: 1 101 -- 4 x 8 = the 32 tiles an XCD runs at a time
+    static const int gm_set = getenv("GRAM_GEMM_GROUPM") ? atoi(getenv("GRAM_GEMM_GROUPM")) : -1;  // A/B hook (0/1: n fastest)
+    const int gm_env = gm_set >= 0 ? gm_set : (ks.np > 1 ? 4 : 6);
     const int ntn_ = ntiles / ((M + 255) / 256);
     const int gm = ntn_ >= 8 && gm_env > 1 && gm_env < 256 ? gm_env : 0;
     // Tile-end epilogues (ABL 7: the split-operand modes) leave every CU storing at the same moment when all workgroups run in step:
