@@ -119,19 +119,35 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
   __shared__ int sel_tok[GRAM_MAX_BEAMS], sel_par[GRAM_MAX_BEAMS], sel_node[GRAM_MAX_BEAMS];
   __shared__ int new_seq[GRAM_MAX_BEAMS * GRAM_MAX_DEC_LEN];
   __shared__ int new_anc[GRAM_MAX_DEC_LEN * GRAM_MAX_BEAMS];
+  __shared__ int s_edge[2 * GRAM_MAX_BEAMS];
+  __shared__ int s_off[GRAM_MAX_BEAMS], s_cnt[GRAM_MAX_BEAMS], s_lr[GRAM_MAX_BEAMS];
 
   const int b = blockIdx.x, tid = threadIdx.x;
   const int K = st.K, T = st.Tmax, R = st.B * K;
   const int row0 = b * K;
   const int t = cur_len - 1;  // decode step whose K/V were just written
 
+  // per beam: first child edge, child count, hidden-state row -- K threads at once (one thread walking the K beams was K dependent
+  // node -> offsets round trips, ~20 us of a 100-us step at K = 20)
+  if (tid < K) {
+    const int nd = st.node[row0 + tid];
+    const int done = st.done[b];
+    int o0 = 0, cnt = 0;
+    if (!done && nd >= 0) {
+      o0 = tr.child_off[nd];
+      cnt = tr.child_off[nd + 1] - o0;
+    }
+    s_off[tid] = o0;
+    s_cnt[tid] = cnt;
+    s_lr[tid] = rowpos ? rowpos[row0 + tid] : row0 + tid;  // live-row step: hidden/lse are indexed by compact row
+    if (tid == 0) s_isdone = done;
+  }
+  __syncthreads();
   if (tid == 0) {
-    s_isdone = st.done[b];
     int acc = 0;
     for (int k = 0; k < K; ++k) {
       s_pre[k] = acc;
-      const int nd = st.node[row0 + k];
-      acc += (s_isdone || nd < 0) ? 0 : (tr.child_off[nd + 1] - tr.child_off[nd]);
+      acc += s_cnt[k];
     }
     s_pre[K] = acc;
     s_C = acc;
@@ -153,17 +169,18 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
     const bool shared0 = rows_per_user == 1;  // step 0: all K beams sit on the same node and the same row
     const int nuniq = shared0 ? s_pre[1] : C;
     const int per = d >> 3;                   // elements per lane
-    for (int base = 0; base < nuniq; base += 32) {
-      const int ci = base + grp;
-      const bool act = ci < nuniq;
-      int k = 0, tok = 0, lr = b;
-      if (act) {
-        if (!shared0) {
-          while (s_pre[k + 1] <= ci) ++k;
-          lr = rowpos ? rowpos[row0 + k] : row0 + k;  // live-row step: hidden/lse are indexed by compact row
-        }
-        tok = tr.child_tok[tr.child_off[st.node[row0 + k]] + (ci - s_pre[k])];
-      }
+    // (beam, token) of every candidate first, all threads at once, parked in the candidate's key slot: the dot products below then
+    // start from LDS instead of a node -> edge -> token chain of global loads per batch
+    for (int ci = tid; ci < nuniq; ci += 256) {
+      int k = 0;
+      if (!shared0)
+        while (s_pre[k + 1] <= ci) ++k;
+      const int tok = tr.child_tok[s_off[k] + (ci - s_pre[k])];
+      keys[ci] = ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)(uint32_t)tok;
+    }
+    __syncthreads();
+    // h[row] . E[tok] on 8 lanes (same sums in the same order whichever trip a candidate falls into)
+    auto dot = [&](bool act, int lr, int tok) -> float {
       float acc = 0.f;
       if (act && emb32) {
         // split-bf16 modes (gram_split_t): h = fp32 sum of its pieces (smallest first), E = the fp32 lm_head row
@@ -233,12 +250,33 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
       acc += __shfl_xor(acc, 1, 64);
       acc += __shfl_xor(acc, 2, 64);
       acc += __shfl_xor(acc, 4, 64);
-      if (act && sub == 0) {
-        if (shared0) {
-          s_log[ci] = acc;
-        } else {
-          const float sc = (acc - lse[lr]) + st.beam_scores[row0 + k];
-          keys[ci] = ((unsigned long long)f2ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(k * V + tok));
+      return acc;
+    };
+    // two candidates per 8-lane group and trip (64 per workgroup): their loads are independent and overlap
+    for (int base = 0; base < nuniq; base += 64) {
+      int ci2[2], k2[2], tok2[2], lr2[2];
+      bool act2[2];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        ci2[w] = base + 32 * w + grp;
+        act2[w] = ci2[w] < nuniq;
+        const unsigned long long kt = act2[w] ? keys[ci2[w]] : 0ull;
+        k2[w] = (int)(kt >> 32);
+        tok2[w] = (int)(kt & 0xffffffffull);
+        lr2[w] = shared0 ? b : s_lr[k2[w]];
+      }
+      float acc2[2];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) acc2[w] = dot(act2[w], lr2[w], tok2[w]);
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        if (act2[w] && sub == 0) {
+          if (shared0) {
+            s_log[ci2[w]] = acc2[w];
+          } else {
+            const float sc = (acc2[w] - lse[lr2[w]]) + st.beam_scores[row0 + k2[w]];
+            keys[ci2[w]] = ((unsigned long long)f2ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(k2[w] * V + tok2[w]));
+          }
         }
       }
     }
@@ -324,6 +362,22 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
     }
   }
 
+  // the Trie edge of every ranked candidate, looked up by 2K threads at once (one binary search each; the walk below ran them one
+  // after the other: up to K dependent searches of ~6 global loads each on a single thread)
+  if (!isdone) {
+    for (int rank = tid; rank < 2 * K; rank += 256) {
+      int e = -1;
+      if (rank < C) {
+        const unsigned long long key = keys[rank];
+        const uint32_t flat = 0xffffffffu - (uint32_t)(key & 0xffffffffull);
+        const int k = (int)(flat / (uint32_t)V), tok = (int)(flat % (uint32_t)V);
+        if (tok != st.eos) e = find_child(tr, st.node[row0 + k], tok);
+      }
+      s_edge[rank] = e;
+    }
+    __syncthreads();
+  }
+
   if (tid == 0) {
     if (isdone) {
       // BeamSearchScorer.process pads a finished user
@@ -358,7 +412,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
           if (rank >= K) continue;
           hyp_add(st, b, st.seq + (size_t)(row0 + k) * T, cur_len, sc);
         } else {
-          const int e = (rank < C) ? find_child(tr, st.node[row0 + k], tok) : -1;
+          const int e = (rank < C) ? s_edge[rank] : -1;
           sel_score[j] = sc;
           sel_tok[j] = tok;
           sel_par[j] = k;
