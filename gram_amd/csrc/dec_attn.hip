@@ -555,7 +555,9 @@ int launch_cross_v(const void* q, const void* k, const void* vt, const uint8_t* 
   // (three or four beam tiles, K > 32: the per-workgroup state is larger and one wave per (user, head) with two stages wins --
   // K = 50, S = 2 688, H = 16: (1, 2) 4.32 / 5.28 TB/s against (2, 1) 3.93 / 4.99, (2, 2) 4.08 / 4.95, (4, 1) 3.66 / 4.75)
   // (a ring of 3 stages per wave for grids of a handful of users was measured too: 12.42 -> 12.67 ms per one-user generate, no gain)
-  if constexpr (NT >= 3) return launch_cross<NT, S, 1, 2>(XA_ARGS);
+  // (with the stage consumed and re-filled in halves, ONE stage wins there too: K = 50, S = 2 688, H = 16, same box: (1, 1) 4.65 / 5.75 TB/s
+  // against (1, 2) 3.97 / 5.12, (4, 1) 4.19 / 5.37, (2, 2) 3.72 / 5.02 -- profiles/r02m_cross_attn_k50_variants.txt)
+  if constexpr (NT >= 3) return launch_cross<NT, S, 1, 1>(XA_ARGS);
   else return launch_cross<NT, S, 2, 1>(XA_ARGS);
 #undef XA_ARGS
 }
