@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restri
                                                             bf16* __restrict__ vcache, const int32_t* __restrict__ anc,
                                                             const float* __restrict__ bias, bf16* __restrict__ out, int R,
                                                             int H, int t, const int32_t* __restrict__ rows, long qkv_ps,
-                                                            long cache_ps, long out_ps, int n_rows) {
+                                                            long cache_ps, long out_ps) {
   // live-row step (rows != NULL): qkv/out are indexed by the compact row, the cache and the ancestor table by the
   // original row rows[compact]; R stays the row count of the cache
   // (giving each XCD a contiguous eighth of the rows, so that a user's beams share ancestors' cache rows in ONE L2, was measured:
@@ -739,15 +739,15 @@ extern "C" int gram_dec_self_attn_split(const void* qkv, void* kcache, void* vca
   switch (pieces) {
     case 1:
       hipLaunchKernelGGL(dec_self_attn_kernel<1>, grid, block, 0, st, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, anc, bias,
-                         (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride, (long)out_pstride, n_rows);
+                         (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride, (long)out_pstride);
       break;
     case 2:
       hipLaunchKernelGGL(dec_self_attn_kernel<2>, grid, block, 0, st, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, anc, bias,
-                         (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride, (long)out_pstride, n_rows);
+                         (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride, (long)out_pstride);
       break;
     default:
       hipLaunchKernelGGL(dec_self_attn_kernel<3>, grid, block, 0, st, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, anc, bias,
-                         (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride, (long)out_pstride, n_rows);
+                         (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride, (long)out_pstride);
       break;
   }
   GRAM_CHECK_LAUNCH();
