@@ -44,3 +44,28 @@ def test_argument_errors_without_gpu():
     assert lib.gram_cross_attn_decode(None, None, None, None, None, 1, 65, 2, 64, None) == _lib.E_ARG
     assert lib.gram_model_create(None) is None
     assert lib.gram_workspace_bytes(None, 1, 1, 32, 1, 4) == _lib.E_ARG
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """Every struct of include/gram_hip.h against its ctypes mirror in gram_amd/_lib.py: total size and the offset of every field,
+    from a C program compiled against the real header (gcc; no GPU)."""
+    import subprocess
+    pairs = {"gram_kv_bank_t": _lib.KVBank, "gram_norm_fusion_t": _lib.NormFusion, "gram_split_t": _lib.Split, "gram_trie_t": _lib.Trie,
+             "gram_beam_state_t": _lib.BeamState, "gram_live_rows_t": _lib.LiveRows, "gram_model_desc_t": _lib.ModelDesc,
+             "gram_compaction_t": _lib.Compaction}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gram_hip.h"', "int main(void) {"]
+    for cname, st in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(ln.split()[:2]): int(ln.split()[2]) for ln in out if ln.strip()}
+    for cname, st in pairs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert got[(cname, fname)] == getattr(st, fname).offset, (cname, fname)
