@@ -44,6 +44,13 @@ def test_argument_errors_without_gpu():
     assert lib.gram_cross_attn_decode(None, None, None, None, None, 1, 65, 2, 64, None) == _lib.E_ARG
     assert lib.gram_model_create(None) is None
     assert lib.gram_workspace_bytes(None, 1, 1, 32, 1, 4) == _lib.E_ARG
+    # 16-column ("quarter") sum-of-squares partials are the streaming small-M GEMM's layout only: refused for more rows than it takes
+    # (the pointers are never dereferenced: the refusal comes before any launch)
+    fake = ctypes.c_void_p(0x1000)
+    big = lib.gram_gemm_stream_max_m() + 1
+    assert big > 1
+    nf = _lib.NormFusion(None, None, 0x1000, 12, 768, 1e-6, 1)
+    assert lib.gram_gemm_bf16_ex(fake, fake, fake, big, 768, 768, 768, 768, _lib.EPI_BF16, None, ctypes.byref(nf), None) == _lib.E_ARG
 
 
 def test_ctypes_structs_match_the_header(tmp_path):
