@@ -73,6 +73,8 @@ def parse():
                     help="passages 1..N-1 of every user are drawn from a pool of this many item prompts, registered with "
                          "GRAM.cache_passages before the warmup (SURVEY.md §8f N2); not the headline configuration")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL on ROCm)")
+    ap.add_argument("--check-allreduce", action="store_true",
+                    help="--gpus > 1: also run the reference's all_reduce(SUM) of the metric sums as a cross-check of the all-gather")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: all ranks use cuda:0 (with --backend gloo; RCCL needs one GPU per rank)")
     return ap.parse_args()
@@ -223,19 +225,24 @@ def main():
         out = step()
     exchange = None
     if distributed:
-        # the eval's one exchange (distributed_runner_gram.py:832-838): all ranks' hit ranks in one fixed-size all-gather
-        # over RCCL/xGMI, cross-checked by the reference's all_reduce(SUM) of the metric sums
-        from gram_amd.runner import all_gather_hit_ranks
+        # the eval's ONE exchange: every rank's packed {user_idx:int32, hit_rank:int16} records in one fixed-width
+        # all_gather_into_tensor over RCCL/xGMI; the reference's all_reduce(SUM) of the metric sums
+        # (distributed_runner_gram.py:832-838) only as a cross-check under --check-allreduce
+        from gram_amd.runner import all_gather_hits
         from gram_amd.utils import evaluate as ev
         cdev = dev if args.backend == "nccl" else torch.device("cpu")
         mine = hit_ranks(out)
-        allr = all_gather_hit_ranks(mine, cdev)
+        rec = all_gather_hits(rank * B + np.arange(B, dtype=np.int32), mine, world * B, cdev)
+        allr = rec["hit_rank"].astype(np.int16)
         names = ["hit@5", "hit@10", "ndcg@5", "ndcg@10"]
         sums = ev.metrics_from_ranks(allr, names, K)
-        local = torch.tensor(ev.metrics_from_ranks(mine, names, K), dtype=torch.float64, device=cdev)
-        dist.all_reduce(local, op=dist.ReduceOp.SUM)
-        assert len(allr) == world * B and np.allclose(local.cpu().numpy(), sums), "all-gather and all-reduce disagree"
-        exchange = {"collective": f"all_gather_into_tensor of {world} x {B} int32 hit ranks + all_reduce(SUM) cross-check, backend {args.backend}",
+        assert len(allr) == world * B and sorted(rec["user_idx"].tolist()) == list(range(world * B)), "records lost in the all-gather"
+        if args.check_allreduce:
+            local = torch.tensor(ev.metrics_from_ranks(mine, names, K), dtype=torch.float64, device=cdev)
+            dist.all_reduce(local, op=dist.ReduceOp.SUM)
+            assert np.allclose(local.cpu().numpy(), sums), "all-gather and all-reduce disagree"
+        exchange = {"collective": f"one all_gather_into_tensor of {world} x {B} packed {{user_idx:int32, hit_rank:int16}} records (6 B each)"
+                                  + (" + all_reduce(SUM) cross-check" if args.check_allreduce else "") + f", backend {args.backend}",
                     "users_gathered": int(len(allr)), "metrics_vs_synthetic_gold": dict(zip(names, (sums / len(allr)).round(6).tolist()))}
     barrier()
     dt = time.perf_counter() - t0

@@ -25,6 +25,9 @@ SPLIT_NPROD = (0, 1, 3, 6)
 SPLIT_A_PIECE = ((), (0,), (0, 1, 0), (0, 2, 1, 1, 0, 0))
 SPLIT_W_PIECE = ((), (0,), (1, 0, 0), (2, 0, 1, 0, 1, 0))
 
+# gram_debug_set_stage_pieces: the stages of a sensitivity sweep (gram_hip.h: enum gram_stage)
+STAGES = ("enc_attn", "enc_ffn", "bank_k", "bank_v", "dec_self", "dec_cross", "dec_ffn", "lm_head")
+
 vp = C.c_void_p
 i32 = C.c_int32
 i64 = C.c_int64
@@ -112,6 +115,7 @@ SIGNATURES = {
     "gram_gemm_stream_max_m": (C.c_int, []),
     "gram_debug_set_live_rows": (C.c_int, [C.c_int]),
     "gram_debug_set_graph": (C.c_int, [C.c_int]),
+    "gram_debug_set_stage_pieces": (C.c_int, [C.POINTER(i32), C.c_int]),
     "gram_debug_stream_read": (C.c_int, [vp, C.c_size_t, vp, vp]),
     "gram_debug_stream_read_variant": (C.c_int, [vp, C.c_size_t, vp, C.c_int, C.c_int, vp]),
     "gram_prof_enable": (C.c_int, [C.c_uint32, C.c_int]),

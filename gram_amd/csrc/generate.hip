@@ -187,12 +187,27 @@ constexpr int kPrecomputedRsRows = 32768;  // = the row count from which gemm.hi
     if (e__) return e__;  \
   } while (0)
 
+// Sensitivity sweeps (gram_debug_set_stage_pieces): stage s computes on its first g_stage_cap[s] pieces only.  Implemented by ZEROING
+// the upper pieces of the stage's activation operands before they are consumed (a zero piece contributes exact zeros to every product
+// it enters, so the arithmetic is that of the smaller piece count; the kernels and their cost are unchanged) -- the weights' upper
+// pieces are zeroed by the caller when it expands them.  Debug only: every cap costs a memset per use.
+int g_stage_cap[GRAM_STAGE_COUNT] = {99, 99, 99, 99, 99, 99, 99, 99};
+int cap_pieces(const Workspace& w, void* buf, int64_t ps, int stage, void* st);
+
 // One Linear of the path on (possibly split) operands: A (pieces a_ps apart) x W (product-expanded when pieces > 1);
 // c_ps = piece stride of whatever bf16 result the epilogue writes (C, xb_out or the bank).
 int linear(const Workspace& w, const void* A, int64_t a_ps, const void* W, void* C, int64_t c_ps, int M, int N, int kc, int lda, int ldc,
            int epi, const gram_kv_bank_t* bank, const gram_norm_fusion_t* nf, void* st) {
   const gram_split_t sp{w.pieces, a_ps, c_ps, c_ps, c_ps};
   return gram_gemm_bf16_split(A, W, C, M, N, kc, lda, ldc, epi, bank, nf, &sp, st);
+}
+
+int cap_pieces(const Workspace& w, void* buf, int64_t ps, int stage, void* st) {
+  for (int p = g_stage_cap[stage] < 1 ? 1 : g_stage_cap[stage]; p < w.pieces; ++p) {
+    hipError_t e = hipMemsetAsync((bf16*)buf + (size_t)p * ps, 0, (size_t)ps * sizeof(bf16), (hipStream_t)st);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
 }
 
 // The encoder layers on P passages (ids/mask [P][L]); leaves the residual stream in w.x rows [0, P*L).
@@ -216,12 +231,17 @@ int encoder_layers(const gram_model* m, const Workspace& w, const int64_t* ids, 
     TRY(gram_embed_ex_split(c.embed_f32, ids, 1, w.x, w.h, w.ss, d / 64, Me, d, w.pieces, w.ps_h, st));
     for (int i = 0; i < c.n_enc_layers; ++i) {
       if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
+      TRY(cap_pieces(w, w.h, w.ps_h, GRAM_STAGE_ENC_ATTN, st));
       TRY(linear(w, w.h, w.ps_h, m->enc_wqkv[i], w.qkv, w.ps_qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr,
                  i == 0 && !pre_rs ? &consume_embed : &consume, st));
+      TRY(cap_pieces(w, w.qkv, w.ps_qkv, GRAM_STAGE_ENC_ATTN, st));
       TRY(gram_enc_self_attn_split(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, w.pieces, w.ps_qkv, w.ps_attn, st));
+      TRY(cap_pieces(w, w.attn, w.ps_attn, GRAM_STAGE_ENC_ATTN, st));
       TRY(linear(w, w.attn, w.ps_attn, m->enc_wo[i], w.x, w.ps_h, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
+      TRY(cap_pieces(w, w.h, w.ps_h, GRAM_STAGE_ENC_FFN, st));
       TRY(linear(w, w.h, w.ps_h, m->enc_wi[i], w.u, w.ps_u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
+      TRY(cap_pieces(w, w.u, w.ps_u, GRAM_STAGE_ENC_FFN, st));
       TRY(linear(w, w.u, w.ps_u, m->enc_wo2[i], w.x, w.ps_h, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
     }
   } else {
@@ -263,6 +283,8 @@ int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const ui
   // every decoder layer's cross K/V in ONE GEMM, scattered into the beam-shared bank
   gram_kv_bank_t bank{w.bank_k, w.bank_vt, c.n_dec_layers, B, H, N * L, pmap, N, L};
   TRY(linear(w, w.h, w.ps_h, c.dec_wkv_x_all, nullptr, w.ps_bank, Me, c.n_dec_layers * 2 * inner, d, d, 0, GRAM_EPI_KV_BANK, &bank, nullptr, st));
+  TRY(cap_pieces(w, w.bank_k, w.ps_bank, GRAM_STAGE_BANK_K, st));
+  TRY(cap_pieces(w, w.bank_vt, w.ps_bank, GRAM_STAGE_BANK_V, st));
   return 0;
 }
 
@@ -302,16 +324,24 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
     TRY(gram_embed_ex_split(c.embed_f32, tokens, 0, w.xd, w.hd, w.ssd, d / 64, R, d, w.pieces, w.ps_hd, st));
     for (int i = 0; i < c.n_dec_layers; ++i) {
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      TRY(cap_pieces(w, w.hd, w.ps_hd, GRAM_STAGE_DEC_SELF, st));
       TRY(linear(w, w.hd, w.ps_hd, m->dec_wqkv[i], w.qkvd, w.ps_qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr,
                  i == 0 && !pre_rs ? &consume_embed : &consume, st));
+      TRY(cap_pieces(w, w.qkvd, w.ps_qkvd, GRAM_STAGE_DEC_SELF, st));
       TRY(self_attn(i, cache_layer));
+      TRY(cap_pieces(w, w.attnd, w.ps_attnd, GRAM_STAGE_DEC_SELF, st));
       TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo[i], w.xd, w.ps_hd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      TRY(cap_pieces(w, w.hd, w.ps_hd, GRAM_STAGE_DEC_CROSS, st));
       TRY(linear(w, w.hd, w.ps_hd, m->dec_wq_x[i], w.qx, w.ps_qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, &consume, st));
+      TRY(cap_pieces(w, w.qx, w.ps_qx, GRAM_STAGE_DEC_CROSS, st));
       TRY(cross_attn(i, bank_layer));
+      TRY(cap_pieces(w, w.attnd, w.ps_attnd, GRAM_STAGE_DEC_CROSS, st));
       TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo_x[i], w.xd, w.ps_hd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      TRY(cap_pieces(w, w.hd, w.ps_hd, GRAM_STAGE_DEC_FFN, st));
       TRY(linear(w, w.hd, w.ps_hd, m->dec_wi[i], w.ud, w.ps_ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
+      TRY(cap_pieces(w, w.ud, w.ps_ud, GRAM_STAGE_DEC_FFN, st));
       TRY(linear(w, w.ud, w.ps_ud, m->dec_wo2[i], w.xd, w.ps_hd, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
     }
   } else {
@@ -332,6 +362,7 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   }
   const float scale = c.tie_word_embeddings ? 1.0f / sqrtf((float)d) : 1.f;  // gram_t5.py:249-252
   TRY(gram_rmsnorm_bf16_split(w.xd, c.dec_final_ln, w.hd, R, d, c.eps, scale, nullptr, 1, 1, nullptr, w.pieces, w.ps_hd, st));
+  TRY(cap_pieces(w, w.hd, w.ps_hd, GRAM_STAGE_LM_HEAD, st));
   const gram_split_t sp{w.pieces, w.ps_hd, 0, 0, 0};
   if (lse_part)  // log-softmax normaliser partials straight from the accumulators; logits may be NULL (not stored)
     TRY(gram_gemm_bf16_lse_split(w.hd, c.lm_head_bf16, logits, lse_part, R, V, d, d, V, &sp, st));
@@ -354,6 +385,12 @@ int search_step(const gram_model* m, const Workspace& w, const gram_trie_t* trie
 }  // namespace
 
 extern "C" int gram_abi_version(void) { return GRAM_ABI_VERSION; }
+
+extern "C" int gram_debug_set_stage_pieces(const int32_t* caps, int n) {
+  if (caps && n != GRAM_STAGE_COUNT) return GRAM_E_ARG;
+  for (int i = 0; i < GRAM_STAGE_COUNT; ++i) g_stage_cap[i] = caps ? (caps[i] < 1 ? 1 : caps[i]) : 99;
+  return 0;
+}
 
 static int g_graph = -1;      // -1: the GRAM_GRAPH environment variable decides (default on)
 extern "C" int gram_debug_set_graph(int on) {

@@ -137,6 +137,7 @@ class GRAM(nn.Module):
         if self._precision not in self.PRECISIONS:
             raise ValueError(f"GRAM_PRECISION={self._precision!r}: choose from {self.PRECISIONS}")
         self._pcache = None  # passage cache: dict(x, canon, keys, perm) on the device
+        self._stage_caps: Dict[str, int] = {}  # sensitivity sweeps only (set_stage_pieces)
 
     # ------------------------------------------------------------------ weights
     def _init_weights(self) -> None:
@@ -190,6 +191,21 @@ class GRAM(nn.Module):
             raise ValueError(f"unknown precision {mode!r}; choose from {self.PRECISIONS}")
         if mode != self._precision:
             self._precision = mode
+            self._invalidate()
+
+    def set_stage_pieces(self, caps: Optional[Dict[str, int]] = None) -> None:
+        """Sensitivity sweeps (tests/precision_population.py): stage -> number of pieces its operands keep, for the stages of
+        ``_lib.STAGES``; the other stages keep the mode's own count.  The kernels and their cost do not change: the upper pieces of
+        a capped stage's weights are zeroed here and those of its activations in generate.hip (gram_debug_set_stage_pieces), which
+        is arithmetically the smaller piece count.  The caps are process-wide in the library; ``None`` / ``{}`` lifts them."""
+        caps = dict(caps or {})
+        for k in caps:
+            if k not in _lib.STAGES:
+                raise ValueError(f"unknown stage {k!r}; choose from {_lib.STAGES}")
+        arr = (C.c_int32 * len(_lib.STAGES))(*[int(caps.get(k, 99)) for k in _lib.STAGES])
+        _lib.check(_lib.load().gram_debug_set_stage_pieces(arr if caps else None, len(_lib.STAGES)), "gram_debug_set_stage_pieces")
+        if caps != self._stage_caps:
+            self._stage_caps = caps
             self._invalidate()
 
     def _invalidate(self) -> None:
@@ -250,9 +266,12 @@ class GRAM(nn.Module):
 
         pieces = self._PIECES[self._precision]
 
-        def b16(t):
+        caps = self._stage_caps
+
+        def b16(t, stage=None, row_caps=None):
             """[out][in] fp32 -> the MFMA weight operand: bf16, or (split modes) the product-expanded [out][nprod*in] matrix
-            whose chunk c holds piece SPLIT_W_PIECE[c] of W = p0 + p1 (+ p2), p_i = bf16(W - p0 - .. - p_{i-1})."""
+            whose chunk c holds piece SPLIT_W_PIECE[c] of W = p0 + p1 (+ p2), p_i = bf16(W - p0 - .. - p_{i-1}).
+            stage / row_caps: sensitivity sweeps (set_stage_pieces) -- pieces >= the stage's cap are zeroed (per row: row_caps)."""
             t = t.to(dev, torch.float32)
             if pieces == 1:
                 t = t.to(torch.bfloat16).contiguous()
@@ -261,6 +280,12 @@ class GRAM(nn.Module):
                 for _ in range(pieces):
                     ps.append(r.to(torch.bfloat16))
                     r -= ps[-1].float()
+                cap = caps.get(stage, 99) if stage else 99
+                for j in range(pieces):
+                    if j >= cap:
+                        ps[j].zero_()
+                    elif row_caps is not None:
+                        ps[j][row_caps.to(dev) <= j] = 0
                 t = torch.cat([ps[j] for j in _lib.SPLIT_W_PIECE[pieces]], dim=1).contiguous()
             keep.append(t)
             return t.data_ptr()
@@ -275,13 +300,13 @@ class GRAM(nn.Module):
         # per row in the GEMM epilogue.  GRAM_FOLD_NORM=0 keeps the separate norm kernels (A/B, debugging).
         fold = os.environ.get("GRAM_FOLD_NORM", "1") != "0" or pieces > 1
 
-        def lin(wname, gname):
+        def lin(wname, gname, stage):
             w = sd[wname].to(dev, torch.float32)
-            return b16(w * sd[gname].to(dev, torch.float32)[None, :]) if fold else b16(w)
+            return b16(w * sd[gname].to(dev, torch.float32)[None, :], stage) if fold else b16(w, stage)
 
-        def qkv(prefix, gname):
+        def qkv(prefix, gname, stage):
             w = torch.cat([sd[prefix + ".q.weight"], sd[prefix + ".k.weight"], sd[prefix + ".v.weight"]], 0).to(dev, torch.float32)
-            return b16(w * sd[gname].to(dev, torch.float32)[None, :]) if fold else b16(w)
+            return b16(w * sd[gname].to(dev, torch.float32)[None, :], stage) if fold else b16(w, stage)
 
         # relative-bias tables: encoder [H][255] by (key - query + 127), decoder [H][32] by distance
         nb, md = c.relative_attention_num_buckets, c.relative_attention_max_distance
@@ -298,31 +323,35 @@ class GRAM(nn.Module):
         wkv_all = torch.cat(
             [torch.cat([sd[dd.format(i) + ".1.EncDecAttention.k.weight"], sd[dd.format(i) + ".1.EncDecAttention.v.weight"]], 0)
              for i in range(nd)], 0)
+        inner_ = H * c.d_kv  # rows of wkv_all: per layer the K rows, then the V rows
+        kv_row_caps = None
+        if "bank_k" in caps or "bank_v" in caps:
+            kv_row_caps = torch.tensor([caps.get("bank_k", 99), caps.get("bank_v", 99)]).repeat_interleave(inner_).repeat(nd)
         desc = _lib.ModelDesc(
             vocab=c.vocab_size, d_model=c.d_model, d_ff=c.d_ff, n_heads=H, n_enc_layers=ne, n_dec_layers=nd,
             max_passages=self.max_item_num + 1, tie_word_embeddings=int(bool(getattr(c, "tie_word_embeddings", True))),
             use_position_embedding=int(self.use_position_embedding), fold_norm=int(fold), eps=float(c.layer_norm_epsilon),
-            embed_f32=f32(sd["shared.weight"]), lm_head_bf16=b16(sd["lm_head.weight"]),
+            embed_f32=f32(sd["shared.weight"]), lm_head_bf16=b16(sd["lm_head.weight"], "lm_head"),
             pos_emb_f32=f32(sd["position_embedding.weight"]) if self.use_position_embedding else None,
             enc_bias_f32=f32(enc_bias), dec_bias_f32=f32(dec_bias),
             enc_final_ln=f32(sd["encoder.encoder.final_layer_norm.weight"]),
             dec_final_ln=f32(sd["decoder.final_layer_norm.weight"]),
             enc_ln1=ptr_array([f32(sd[e.format(i) + ".0.layer_norm.weight"]) for i in range(ne)]),
-            enc_wqkv=ptr_array([qkv(e.format(i) + ".0.SelfAttention", e.format(i) + ".0.layer_norm.weight") for i in range(ne)]),
-            enc_wo=ptr_array([b16(sd[e.format(i) + ".0.SelfAttention.o.weight"]) for i in range(ne)]),
+            enc_wqkv=ptr_array([qkv(e.format(i) + ".0.SelfAttention", e.format(i) + ".0.layer_norm.weight", "enc_attn") for i in range(ne)]),
+            enc_wo=ptr_array([b16(sd[e.format(i) + ".0.SelfAttention.o.weight"], "enc_attn") for i in range(ne)]),
             enc_ln2=ptr_array([f32(sd[e.format(i) + ".1.layer_norm.weight"]) for i in range(ne)]),
-            enc_wi=ptr_array([lin(e.format(i) + ".1.DenseReluDense.wi.weight", e.format(i) + ".1.layer_norm.weight") for i in range(ne)]),
-            enc_wo2=ptr_array([b16(sd[e.format(i) + ".1.DenseReluDense.wo.weight"]) for i in range(ne)]),
+            enc_wi=ptr_array([lin(e.format(i) + ".1.DenseReluDense.wi.weight", e.format(i) + ".1.layer_norm.weight", "enc_ffn") for i in range(ne)]),
+            enc_wo2=ptr_array([b16(sd[e.format(i) + ".1.DenseReluDense.wo.weight"], "enc_ffn") for i in range(ne)]),
             dec_ln1=ptr_array([f32(sd[dd.format(i) + ".0.layer_norm.weight"]) for i in range(nd)]),
-            dec_wqkv=ptr_array([qkv(dd.format(i) + ".0.SelfAttention", dd.format(i) + ".0.layer_norm.weight") for i in range(nd)]),
-            dec_wo=ptr_array([b16(sd[dd.format(i) + ".0.SelfAttention.o.weight"]) for i in range(nd)]),
+            dec_wqkv=ptr_array([qkv(dd.format(i) + ".0.SelfAttention", dd.format(i) + ".0.layer_norm.weight", "dec_self") for i in range(nd)]),
+            dec_wo=ptr_array([b16(sd[dd.format(i) + ".0.SelfAttention.o.weight"], "dec_self") for i in range(nd)]),
             dec_ln2=ptr_array([f32(sd[dd.format(i) + ".1.layer_norm.weight"]) for i in range(nd)]),
-            dec_wq_x=ptr_array([lin(dd.format(i) + ".1.EncDecAttention.q.weight", dd.format(i) + ".1.layer_norm.weight") for i in range(nd)]),
-            dec_wo_x=ptr_array([b16(sd[dd.format(i) + ".1.EncDecAttention.o.weight"]) for i in range(nd)]),
+            dec_wq_x=ptr_array([lin(dd.format(i) + ".1.EncDecAttention.q.weight", dd.format(i) + ".1.layer_norm.weight", "dec_cross") for i in range(nd)]),
+            dec_wo_x=ptr_array([b16(sd[dd.format(i) + ".1.EncDecAttention.o.weight"], "dec_cross") for i in range(nd)]),
             dec_ln3=ptr_array([f32(sd[dd.format(i) + ".2.layer_norm.weight"]) for i in range(nd)]),
-            dec_wi=ptr_array([lin(dd.format(i) + ".2.DenseReluDense.wi.weight", dd.format(i) + ".2.layer_norm.weight") for i in range(nd)]),
-            dec_wo2=ptr_array([b16(sd[dd.format(i) + ".2.DenseReluDense.wo.weight"]) for i in range(nd)]),
-            dec_wkv_x_all=b16(wkv_all),
+            dec_wi=ptr_array([lin(dd.format(i) + ".2.DenseReluDense.wi.weight", dd.format(i) + ".2.layer_norm.weight", "dec_ffn") for i in range(nd)]),
+            dec_wo2=ptr_array([b16(sd[dd.format(i) + ".2.DenseReluDense.wo.weight"], "dec_ffn") for i in range(nd)]),
+            dec_wkv_x_all=b16(wkv_all, None, kv_row_caps),
             pieces=pieces, lm_head_f32=f32(sd["lm_head.weight"]) if pieces > 1 else None,
         )
         handle = lib.gram_model_create(C.byref(desc))

@@ -1,6 +1,6 @@
 """``get_runner`` with the reference's dispatch and error behaviour (src/runner/__init__.py:12-58)."""
 from .base import BaseRunner
-from .distributed_runner_gram import DistributedRunnerGRAM, ShardSampler, all_gather_hit_ranks, shard_indices
+from .distributed_runner_gram import DistributedRunnerGRAM, HIT_RECORD, ShardSampler, all_gather_hit_ranks, all_gather_hits, shard_indices
 from .single_runner_gram import SingleRunnerGRAM
 
 
@@ -14,4 +14,4 @@ def get_runner(runner_type, model_rec, model_gen, tokenizer, train_loader_id, tr
     raise ValueError(f"Unknown runner type: {runner_type}")
 
 
-__all__ = ["get_runner", "BaseRunner", "SingleRunnerGRAM", "DistributedRunnerGRAM", "shard_indices", "all_gather_hit_ranks", "ShardSampler"]
+__all__ = ["get_runner", "BaseRunner", "SingleRunnerGRAM", "DistributedRunnerGRAM", "shard_indices", "all_gather_hit_ranks", "all_gather_hits", "HIT_RECORD", "ShardSampler"]

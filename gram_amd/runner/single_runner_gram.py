@@ -23,9 +23,16 @@ class SingleRunnerGRAM(BaseRunner):
             logging.info(f"{mode} {name}: {val}")  # single_runner_gram.py:708
         n_batches = max(len(testloader), 1)
         logging.info(f"Total inference time: {total_time:.2f}s for {n_batches} samples. Average: {total_time / n_batches:.4f}s")
+        self.last_pred_file = None
         if _arg(self.args, "save_predictions", False):
-            self._write_preds(_arg(self.args, "pred_path", f"../preds/{testloader.dataset.dataset}_pred_{mode}.tsv"), user_ids,
-                              ranks, rows_out, footer=metrics_res.tolist())
+            # single_runner_gram.py:580-588: ../preds/{timestamp}_{dataset}_{task}_pred_{mode}.tsv (--pred_dir / --pred_path: extensions)
+            import datetime
+            import os
+            stamp = datetime.datetime.now().strftime("%Y%m%d_%H%M%S")
+            fname = _arg(self.args, "pred_path", None) or os.path.join(
+                _arg(self.args, "pred_dir", "../preds"), f"{stamp}_{testloader.dataset.dataset}_{testloader.dataset.task}_pred_{mode}.tsv")
+            self._write_preds(fname, user_ids, ranks, rows_out, footer=metrics_res.tolist())
+            self.last_pred_file = fname
         self.last_results = dict(metrics=dict(zip(self.metrics, metrics_res.tolist())), sums=sums, total=test_total,
                                  hit_ranks=ranks, generate_seconds=total_time,
                                  users_per_sec=test_total / total_time if total_time > 0 else float("nan"))

@@ -448,6 +448,22 @@ int gram_debug_set_live_rows(int on);
  * measured without gain on MI355X, see generate.hip). */
 int gram_debug_set_graph(int on);
 
+/* Sensitivity sweeps over the split modes (tests/precision_population.py --sweep): stage s of a generate() computes on the first
+ * caps[s] pieces of its operands only (the upper pieces of its activation operands are zeroed before use; the caller zeroes the
+ * upper pieces of that stage's weights when it expands them).  caps NULL = no caps.  n must be GRAM_STAGE_COUNT. */
+enum gram_stage {
+  GRAM_STAGE_ENC_ATTN = 0,  /* encoder QKV GEMM, self-attention, O GEMM                    */
+  GRAM_STAGE_ENC_FFN = 1,   /* encoder wi / wo GEMMs                                       */
+  GRAM_STAGE_BANK_K = 2,    /* the stored K bank (and the K rows of the bank projection)    */
+  GRAM_STAGE_BANK_V = 3,    /* the stored V^T bank (and the V rows of the bank projection)  */
+  GRAM_STAGE_DEC_SELF = 4,  /* decoder QKV GEMM, cached self-attention, O GEMM             */
+  GRAM_STAGE_DEC_CROSS = 5, /* decoder cross-attention q GEMM, the query side, O GEMM      */
+  GRAM_STAGE_DEC_FFN = 6,   /* decoder wi / wo GEMMs                                       */
+  GRAM_STAGE_LM_HEAD = 7,   /* final hidden state: lm_head GEMM (LSE) and the sparse logits */
+  GRAM_STAGE_COUNT = 8
+};
+int gram_debug_set_stage_pieces(const int32_t* caps, int n);
+
 int gram_abi_version(void);
 
 #ifdef __cplusplus

@@ -130,6 +130,18 @@ def summarise(acc):
     }
 
 
+def parse_mode(spec):
+    """'bf16x6' or 'bf16x6/enc_attn=1+bank_v=2' (stage caps of a sensitivity sweep, GRAM.set_stage_pieces)."""
+    mode, _, caps = spec.partition("/")
+    return mode, {k: int(v) for k, v in (kv.split("=") for kv in caps.split("+") if kv)}
+
+
+def sweep_modes(base, pieces):
+    """Every stage at 1 .. pieces-1 pieces with the rest at `base` (plus `base` itself)."""
+    from gram_amd import _lib
+    return [base] + [f"{base}/{st}={n}" for st in _lib.STAGES for n in range(1, pieces)]
+
+
 def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("bf16",), seed=2023, sharpen=1.0, N=3, L=128, K=20,
         dev="cuda:0", log=print, n_items=0):
     from gram_amd.utils import generation_trie as gt
@@ -151,27 +163,38 @@ def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("bf1
     accs = {m: new_acc() for m in modes}
     t_ref = t_dev = 0.0
     g = torch.Generator().manual_seed(seed + 1)
+    # pass 1: the fp32 reference of every chunk (kept on the host: K sequences + scores per user); pass 2: one mode at a time over all
+    # the chunks, so that the weights are re-packed once per mode (a sweep runs dozens of modes)
+    chunks = []
     for u0 in range(0, users, chunk):
         B = min(chunk, users - u0)
         ids = torch.randint(2, vmax, (B, N, L), generator=g)
         ids[:, :, -1] = 1
         mask = torch.ones(B, N, L, dtype=torch.bool)
-        ids_d, mask_d = ids.to(dev), mask.to(dev)
         t0 = time.perf_counter()
-        ref = O.generate(sd, oc, ids_d, mask_d, max_length, ofn, K, K, 1.0)
+        ref = O.generate(sd, oc, ids.to(dev), mask.to(dev), max_length, ofn, K, K, 1.0)
         torch.cuda.synchronize()
         t_ref += time.perf_counter() - t0
-        for m in modes:
-            model.set_precision(m)
-            t0 = time.perf_counter()
-            out = model.generate(input_ids=ids_d, attention_mask=mask_d, max_length=max_length, prefix_allowed_tokens_fn=dfn,
+        chunks.append((u0, B, ids, mask, ref["sequences"].cpu(), ref["sequences_scores"].cpu()))
+        log(f"[precision] reference users {u0 + B}/{users}  {t_ref:.0f}s")
+    del sd
+    torch.cuda.empty_cache()
+    for m in modes:
+        mode, caps = parse_mode(m)
+        model.set_precision(mode)
+        model.set_stage_pieces(caps)
+        t0 = time.perf_counter()
+        for u0, B, ids, mask, rseq, rsc in chunks:
+            out = model.generate(input_ids=ids.to(dev), attention_mask=mask.to(dev), max_length=max_length, prefix_allowed_tokens_fn=dfn,
                                  num_beams=K, num_return_sequences=K, length_penalty=1.0)
-            torch.cuda.synchronize()
-            t_dev += time.perf_counter() - t0
-            compare(ref["sequences"].cpu(), ref["sequences_scores"].cpu(), out["sequences"].cpu(), out["sequences_scores"].cpu(),
-                    B, K, u0, accs[m])
-        log(f"[precision] users {u0 + B}/{users}  ref {t_ref:.0f}s dev {t_dev:.0f}s  " +
-            "  ".join(f"{m}: flips {a['flips']} max|ds| {a['max_score_dev']:.2e}" for m, a in accs.items()))
+            compare(rseq, rsc, out["sequences"].cpu(), out["sequences_scores"].cpu(), B, K, u0, accs[m])
+        torch.cuda.synchronize()
+        t_dev += time.perf_counter() - t0
+        a = accs[m]
+        log(f"[precision] {m}: flips {a['flips']} membership {a['membership_changes']} max|ds| {a['max_score_dev']:.2e} "
+            f"|dhit@5| {abs(a['o_sum'][0] - a['d_sum'][0]) / max(a['users'], 1):.2e} |dndcg@5| {abs(a['o_sum'][1] - a['d_sum'][1]) / max(a['users'], 1):.2e}"
+            f"  (dev {t_dev:.0f}s)")
+    model.set_stage_pieces(None)
     return {
         "population": {"backbone": backbone, "dataset": dataset, "items": len(cands), "users": users, "N": N, "L": L, "K": K,
                        "seed": seed, "q_sharpen": sharpen, "gold_rank": "reference rank (user index mod 10)",
@@ -191,8 +214,13 @@ def main():
     ap.add_argument("--sharpen", type=float, default=1.0)
     ap.add_argument("--beams", type=int, default=20)
     ap.add_argument("--out", default="")
+    ap.add_argument("--sweep", default="", help="BASE mode: every stage at fewer pieces with the rest at BASE (per-stage sensitivity)")
     a = ap.parse_args()
-    res = run(a.users, a.chunk, a.backbone, a.dataset, tuple(a.modes.split(",")), a.seed, a.sharpen, K=a.beams)
+    modes = tuple(a.modes.split(","))
+    if a.sweep:
+        import gram_amd
+        modes = tuple(sweep_modes(a.sweep, gram_amd.GRAM._PIECES[a.sweep]))
+    res = run(a.users, a.chunk, a.backbone, a.dataset, modes, a.seed, a.sharpen, K=a.beams)
     txt = json.dumps(res, indent=1)
     print(txt)
     if a.out:
