@@ -18,12 +18,25 @@ GRAM_MAX_PASSAGE_LEN = 128
 EPI_BF16, EPI_BF16_RELU, EPI_F32_ADD, EPI_F32, EPI_KV_BANK = range(5)
 K_GEMM, K_ENC_ATTN, K_CROSS_ATTN, K_DEC_SELF_ATTN, K_ROWOPS, K_LSE, K_BEAM = range(7)
 E_ARG, E_WORKSPACE, E_BEAM = -1, -2, -3
-ABI_VERSION = 4
-# split-bf16 precision modes (gram_hip.h: GRAM_SPLIT_*): bf16 pieces per value -> products, and the (A piece, W piece) of each
-MAX_PIECES = 3
-SPLIT_NPROD = (0, 1, 3, 6)
-SPLIT_A_PIECE = ((), (0,), (0, 1, 0), (0, 2, 1, 1, 0, 0))
-SPLIT_W_PIECE = ((), (0,), (1, 0, 0), (2, 0, 1, 0, 1, 0))
+ABI_VERSION = 5
+# two-piece mode (gram_hip.h, gram_split_t): 16-bit pieces per value -> MFMA products per product
+MAX_PIECES = 2
+SPLIT_NPROD = (0, 1, 3)
+
+
+def interleave(pieces):
+    """[2][rows][cols] pieces -> the interleaved [rows][2 * cols] matrix a GEMM reads (gram_hip.h): per 32-column block, piece 0's
+    32 values then piece 1's."""
+    p, rows, cols = pieces.shape
+    assert p == 2 and cols % 32 == 0
+    return pieces.view(2, rows, cols // 32, 32).permute(1, 2, 0, 3).reshape(rows, 2 * cols).contiguous()
+
+
+def deinterleave(x):
+    """inverse of ``interleave``: [rows][2 * cols] -> [2][rows][cols]"""
+    rows, c2 = x.shape
+    return x.view(rows, c2 // 64, 2, 32).permute(2, 0, 1, 3).reshape(2, rows, c2 // 2).contiguous()
+
 
 # gram_debug_set_stage_pieces: the stages of a sensitivity sweep (gram_hip.h: enum gram_stage)
 STAGES = ("enc_attn", "enc_ffn", "bank_k", "bank_v", "dec_self", "dec_cross", "dec_ffn", "lm_head")
@@ -55,7 +68,7 @@ class BeamState(C.Structure):
 
 
 class Split(C.Structure):
-    _fields_ = [("pieces", i32), ("a_pstride", i64), ("c_pstride", i64), ("xb_pstride", i64), ("bank_pstride", i64)]
+    _fields_ = [("pieces", i32), ("c_interleaved", i32), ("c_pstride", i64), ("bank_pstride", i64), ("out_scale", f32)]
 
 
 class NormFusion(C.Structure):
@@ -80,13 +93,14 @@ class ModelDesc(C.Structure):
         ("dec_ln2", C.POINTER(vp)), ("dec_wq_x", C.POINTER(vp)), ("dec_wo_x", C.POINTER(vp)),
         ("dec_ln3", C.POINTER(vp)), ("dec_wi", C.POINTER(vp)), ("dec_wo2", C.POINTER(vp)),
         ("dec_wkv_x_all", vp),
-        ("pieces", i32), ("lm_head_f32", vp),
+        ("pieces", i32), ("lm_head_f32", vp), ("w_scales", C.POINTER(f32)),
     ]
 
 
 # name -> (restype, argtypes); every symbol include/gram_hip.h declares
 SIGNATURES = {
     "gram_abi_version": (C.c_int, []),
+    "gram_piece_format": (C.c_int, []),
     "gram_gemm_bf16": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KVBank), vp]),
     "gram_gemm_bf16_ex": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KVBank), C.POINTER(NormFusion), vp]),
     "gram_row_rscale": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
@@ -133,16 +147,14 @@ SIGNATURES = {
     "gram_gemm_bf16_split": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KVBank),
                                        C.POINTER(NormFusion), C.POINTER(Split), vp]),
     "gram_gemm_bf16_lse_split": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Split), vp]),
-    "gram_embed_ex_split": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, vp]),
-    "gram_rmsnorm_bf16_split": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, f32, f32, vp, C.c_int, C.c_int, vp, C.c_int, i64, vp]),
-    "gram_enc_self_attn_split": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64, vp]),
-    "gram_cross_attn_decode_split": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, i64, i64, i64, vp,
-                                               vp]),
+    "gram_embed_ex_split": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "gram_rmsnorm_bf16_split": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, f32, f32, vp, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "gram_enc_self_attn_split": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, vp]),
+    "gram_cross_attn_decode_split": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, i64, i64, vp, vp]),
     "gram_mask_key_bits": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
-    "gram_dec_self_attn_split": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64,
-                                           i64, vp]),
+    "gram_dec_self_attn_split": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64, vp]),
     "gram_beam_step_sparse_split": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int,
-                                              vp, C.c_int, i64, vp]),
+                                              vp, C.c_int, vp]),
     "gram_generate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.POINTER(Trie),
                                 vp, i64, vp, vp, C.POINTER(i32), vp]),
 }
@@ -177,6 +189,13 @@ def load() -> C.CDLL:
 
 class GramHipError(RuntimeError):
     pass
+
+
+def piece_dtype():
+    """torch dtype of the loaded library's 16-bit operands (gram_piece_format(): float16 for the default build, bfloat16 for
+    ``make PIECE=bf16``)."""
+    import torch
+    return torch.float16 if load().gram_piece_format() == 1 else torch.bfloat16
 
 
 def check(code: int, what: str) -> None:

@@ -108,7 +108,7 @@ __global__ void beam_init_kernel(gram_beam_state_t st, gram_trie_t tr, int start
 __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gram_trie_t tr, const float* __restrict__ logits,
                                                         const float* __restrict__ lse, int V, int cur_len, int nc_max, int rows_per_user,
                                                         const bf16* __restrict__ hd, const bf16* __restrict__ emb, int d,
-                                                        const int32_t* __restrict__ rowpos, int pieces, long hd_pstride,
+                                                        const int32_t* __restrict__ rowpos, int pieces,
                                                         const float* __restrict__ emb32) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [nc_max]
@@ -183,8 +183,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
     auto dot = [&](bool act, int lr, int tok) -> float {
       float acc = 0.f;
       if (act && emb32) {
-        // split-bf16 modes (gram_split_t): h = fp32 sum of its pieces (smallest first), E = the fp32 lm_head row
-        const bf16* hp = hd + (size_t)lr * d + sub * per;
+        // two-piece mode (gram_split_t): h = fp32 sum of its pieces (smallest first; the row is interleaved, [2 d]), E = the fp32 lm_head row
+        const bf16* hrow = hd + (size_t)lr * d * pieces;
+        const int c0 = sub * per;
+        auto hoff = [&](int n, int pc) { return pieces == 2 ? inter_off(n, pc) : n; };
         const f32x4* ep = reinterpret_cast<const f32x4*>(emb32 + (size_t)tok * d + sub * per);
         int i = 0;
         if (pieces <= 2) {
@@ -195,8 +197,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
             f32x4 ev[8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              hb0[u] = ld_global_b128(hp + i + 8 * u);
-              hb1[u] = pieces == 2 ? ld_global_b128(hp + hd_pstride + i + 8 * u) : zero_bf16x8();
+              hb0[u] = ld_global_b128(hrow + hoff(c0 + i + 8 * u, 0));
+              hb1[u] = pieces == 2 ? ld_global_b128(hrow + hoff(c0 + i + 8 * u, 1)) : zero_bf16x8();
               ev[2 * u] = ep[(i >> 2) + 2 * u];
               ev[2 * u + 1] = ep[(i >> 2) + 2 * u + 1];
             }
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
         for (; i < per; i += 8) {
           float hv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           for (int pc = pieces - 1; pc >= 0; --pc) {
-            const bf16x8 hb = ld_global_b128(hp + pc * hd_pstride + i);
+            const bf16x8 hb = ld_global_b128(hrow + hoff(c0 + i, pc));
 #pragma unroll
             for (int e = 0; e < 8; ++e) hv[e] += (float)hb[e];
           }
@@ -633,11 +635,11 @@ extern "C" int gram_beam_init(const gram_beam_state_t* st, const gram_trie_t* tr
 
 static int launch_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, const float* logits, const float* lse, int V,
                             int cur_len, int rows_per_user, const void* hd, const void* emb, int d, const int32_t* rowpos,
-                            void* stream, int pieces = 1, long hd_pstride = 0, const float* emb32 = nullptr) {
+                            void* stream, int pieces = 1, const float* emb32 = nullptr) {
   if (int e = check_state(st)) return e;
   if (!tr || !lse || cur_len < 1 || cur_len >= st->Tmax || V < 2 || (rows_per_user != 1 && rows_per_user != st->K)) return GRAM_E_ARG;
   if (!logits && (!hd || (!emb && !emb32) || d < 64 || (d & 63))) return GRAM_E_ARG;
-  if (pieces < 1 || pieces > GRAM_MAX_PIECES || (pieces > 1 && (!emb32 || hd_pstride < 1))) return GRAM_E_ARG;
+  if (pieces < 1 || pieces > GRAM_MAX_PIECES || (pieces > 1 && (!emb32 || (d & 63)))) return GRAM_E_ARG;  // (8 lanes x 8-element loads inside 32-column blocks)
   long long need = (long long)st->K * tr->max_fanout;
   int nc = 64;
   while (nc < need) nc <<= 1;
@@ -652,7 +654,7 @@ static int launch_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, 
   }
   gram_prof::Scope prof(GRAM_K_BEAM, (hipStream_t)stream, 0.0);
   hipLaunchKernelGGL(beam_step_kernel, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc,
-                     rows_per_user, (const bf16*)hd, (const bf16*)emb, d, rowpos, pieces, hd_pstride, emb32);
+                     rows_per_user, (const bf16*)hd, (const bf16*)emb, d, rowpos, pieces, emb32);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -678,10 +680,9 @@ extern "C" int gram_beam_step_sparse_live(const gram_beam_state_t* st, const gra
 
 extern "C" int gram_beam_step_sparse_split(const gram_beam_state_t* st, const gram_trie_t* tr, const void* hidden_bf16,
                                            const float* lm_head_f32, int d, const float* lse, int V, int cur_len, int rows_per_user,
-                                           const int32_t* rowpos, int pieces, int64_t hidden_pstride, void* stream) {
+                                           const int32_t* rowpos, int pieces, void* stream) {
   if (!lm_head_f32) return GRAM_E_ARG;
-  return launch_beam_step(st, tr, nullptr, lse, V, cur_len, rows_per_user, hidden_bf16, nullptr, d, rowpos, stream, pieces,
-                          (long)hidden_pstride, lm_head_f32);
+  return launch_beam_step(st, tr, nullptr, lse, V, cur_len, rows_per_user, hidden_bf16, nullptr, d, rowpos, stream, pieces, lm_head_f32);
 }
 
 extern "C" int gram_live_rows(const gram_beam_state_t* st, const gram_trie_t* tr, const gram_live_rows_t* out, void* stream) {

@@ -4,10 +4,27 @@
 #include <stdint.h>
 #include "../../include/gram_hip.h"
 
+// The 16-bit operand type of every MFMA on the path: IEEE half.  11 significant bits per piece instead of bfloat16's 8, so the
+// two-piece mode reaches ~2^-22 instead of ~2^-18 at the same MFMA rate (v_mfma_f32_16x16x32_f16 runs at the bf16 rate and keeps
+// f16 subnormal inputs: profiles/r03_mfma_f16_denorm_probe.json) -- measured: no rank flip against the fp32 reference on either
+// test population, where two bf16 pieces flip (profiles/r03a_precision_*).  The narrower exponent range is handled by power-of-two
+// weight scales (gram_split_t.out_scale).  `make PIECE=bf16` (GRAM_PIECE_BF16) builds the same sources on bfloat16 for A/B runs.
+// The identifier of the type is `bf16` in both builds (as in the C ABI's entry-point names, which predate the switch).
+#ifdef GRAM_PIECE_BF16
 typedef __bf16 bf16;
+#define GRAM_PIECE_FORMAT 0
+#else
+typedef _Float16 bf16;
+#define GRAM_PIECE_FORMAT 1
+#define GRAM_F16 1
+#endif
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// largest M the streaming small-M GEMM ever takes (gemm.hip clamps GRAM_GEMM_STREAM_MAXM to it; generate.hip sizes the 16-column
+// sum-of-squares partial buffers for it)
+constexpr int GRAM_STREAM_MAX_M_LIMIT = 4096;
 
 #define GRAM_FMIN (-3.4028234663852886e38f)  // torch.finfo(float32).min, gram_t5_modeling.py:1130-1132
 #define WAVE 64
@@ -21,7 +38,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // D[16x16] += A[16x32] * B[32x16]; lane l supplies A[row l&15][k 8(l>>4)..+7], B[k 8(l>>4)..+7][col l&15];
 // lane l receives D[row 4(l>>4)+j][col l&15] in element j.
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+#ifdef GRAM_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ bf16x8 ld_global_b128(const bf16* p) {
@@ -48,11 +69,14 @@ __device__ __forceinline__ bf16x8 zero_bf16x8() {
   return z;
 }
 
-// products of the split-bf16 modes (gram_hip.h: GRAM_SPLIT_A_PIECE / GRAM_SPLIT_W_PIECE), smallest first
+// products of the two-piece mode (gram_hip.h, gram_split_t): (A piece, B piece) pairs, smallest first
 template <int S> struct SplitTab;
-template <> struct SplitTab<1> { static constexpr int NP = 1; static constexpr int A[6] = {0, 0, 0, 0, 0, 0}; static constexpr int B[6] = {0, 0, 0, 0, 0, 0}; };
-template <> struct SplitTab<2> { static constexpr int NP = 3; static constexpr int A[6] = {0, 1, 0, 0, 0, 0}; static constexpr int B[6] = {1, 0, 0, 0, 0, 0}; };
-template <> struct SplitTab<3> { static constexpr int NP = 6; static constexpr int A[6] = {0, 2, 1, 1, 0, 0}; static constexpr int B[6] = {2, 0, 1, 0, 1, 0}; };
+template <> struct SplitTab<1> { static constexpr int NP = 1; static constexpr int A[3] = {0, 0, 0}; static constexpr int B[3] = {0, 0, 0}; };
+template <> struct SplitTab<2> { static constexpr int NP = 3; static constexpr int A[3] = {0, 1, 0}; static constexpr int B[3] = {1, 0, 0}; };
+
+// element offset of (column n, piece pc) inside a row of an INTERLEAVED two-piece matrix [rows][cols / 32][2][32] (gram_hip.h): the
+// layout of every 16-bit operand a GEMM reads in the two-piece mode
+__device__ __forceinline__ int inter_off(int n, int pc) { return ((n >> 5) << 6) + pc * 32 + (n & 31); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

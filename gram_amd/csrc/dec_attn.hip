@@ -60,7 +60,7 @@ template <int NT, bool LIVE, int S, int NW, int R>
 __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     const bf16* __restrict__ q, const bf16* __restrict__ kbank, const bf16* __restrict__ vtbank,
     const uint8_t* __restrict__ mask, bf16* __restrict__ out, int K, int H, int Sk, const int32_t* __restrict__ users,
-    const int32_t* __restrict__ rowpos, long q_pstride, long bank_pstride, long out_pstride, const uint32_t* __restrict__ key_bits) {
+    const int32_t* __restrict__ rowpos, long q_pstride, long bank_pstride, const uint32_t* __restrict__ key_bits) {
   using T = SplitTab<S>;
   constexpr int NB = NT * 16;                     // padded beams
   constexpr int STAGE = S * 2 * XA_TILE;          // per wave and ring slot: S x (K tile | V^T tile)
@@ -417,7 +417,8 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
               r[e] = (bf16)v[e];
               v[e] -= (float)r[e];
             }
-            *reinterpret_cast<bf16x4*>(out + pc * out_pstride + (size_t)orow * inner + h * 64 + 16 * mt + 4 * g) = r;
+            const int n = h * 64 + 16 * mt + 4 * g;  // (S == 2: interleaved rows [2 * inner], the O GEMM's A operand)
+            *reinterpret_cast<bf16x4*>(out + (size_t)orow * inner * S + (S == 2 ? inter_off(n, pc) : n)) = r;
           }
         }
       }
@@ -467,7 +468,8 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
           r[e] = (bf16)v[e];
           v[e] -= (float)r[e];
         }
-        *reinterpret_cast<bf16x4*>(out + pc * out_pstride + (size_t)orow * inner + h * 64 + d4) = r;
+        const int n = h * 64 + d4;
+        *reinterpret_cast<bf16x4*>(out + (size_t)orow * inner * S + (S == 2 ? inter_off(n, pc) : n)) = r;
       }
     }
   }
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
 
 template <int NT, int S, int NW, int R>
 int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int Sk,
-                 const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, long out_ps, const uint32_t* key_bits, hipStream_t st) {
+                 const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, const uint32_t* key_bits, hipStream_t st) {
   constexpr int NB = NT * 16;
   constexpr int ring = NW * R * S * 2 * XA_TILE, merge = NW == 1 ? 0 : (2 * NW * NB + NW * NB * 64) * 4;
   constexpr int smem = ring > merge ? ring : merge;
@@ -492,10 +494,10 @@ int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* ma
   }
   if (users)
     hipLaunchKernelGGL((cross_attn_kernel<NT, true, S, NW, R>), dim3(H, B), dim3(NW * 64), smem, st, (const bf16*)q, (const bf16*)k,
-                       (const bf16*)vt, mask, (bf16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits);
+                       (const bf16*)vt, mask, (bf16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits);
   else
     hipLaunchKernelGGL((cross_attn_kernel<NT, false, S, NW, R>), dim3(H, B), dim3(NW * 64), smem, st, (const bf16*)q, (const bf16*)k,
-                       (const bf16*)vt, mask, (bf16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits);
+                       (const bf16*)vt, mask, (bf16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -507,8 +509,8 @@ int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* ma
 #endif
 template <int NT, int S>
 int launch_cross_v(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int Sk,
-                   const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, long out_ps, const uint32_t* key_bits, hipStream_t st) {
-#define XA_ARGS q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits, st
+                   const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, const uint32_t* key_bits, hipStream_t st) {
+#define XA_ARGS q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits, st
 #if GRAM_XA_AB
   static const int v = getenv("GRAM_XA_VARIANT") ? atoi(getenv("GRAM_XA_VARIANT")) : 0;
   if constexpr (NT == 2 && S == 1) {
@@ -564,12 +566,12 @@ int launch_cross_v(const void* q, const void* k, const void* vt, const uint8_t* 
 
 template <int S>
 int launch_cross_nt(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int Sk,
-                    const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, long out_ps, const uint32_t* key_bits, hipStream_t st) {
+                    const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, const uint32_t* key_bits, hipStream_t st) {
   switch ((K + 15) / 16) {
-    case 1: return launch_cross_v<1, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits, st);
-    case 2: return launch_cross_v<2, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits, st);
-    case 3: return launch_cross_v<3, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits, st);
-    default: return launch_cross_v<4, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, out_ps, key_bits, st);
+    case 1: return launch_cross_v<1, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits, st);
+    case 2: return launch_cross_v<2, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits, st);
+    case 3: return launch_cross_v<3, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits, st);
+    default: return launch_cross_v<4, S>(q, k, vt, mask, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits, st);
   }
 }
 
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restri
                                                             bf16* __restrict__ vcache, const int32_t* __restrict__ anc,
                                                             const float* __restrict__ bias, bf16* __restrict__ out, int R,
                                                             int H, int t, const int32_t* __restrict__ rows, long qkv_ps,
-                                                            long cache_ps, long out_ps) {
+                                                            long cache_ps) {
   // live-row step (rows != NULL): qkv/out are indexed by the compact row, the cache and the ancestor table by the
   // original row rows[compact]; R stays the row count of the cache
   // (giving each XCD a contiguous eighth of the rows, so that a user's beams share ancestors' cache rows in ONE L2, was measured:
@@ -682,7 +684,8 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restri
       o[e] = (bf16)acc[e];
       acc[e] -= (float)o[e];
     }
-    *reinterpret_cast<bf16x4*>(out + pc * out_ps + (size_t)rc * inner + 4 * i) = o;
+    // (S == 2: interleaved rows [2 * inner], the O GEMM's A operand)
+    *reinterpret_cast<bf16x4*>(out + (size_t)rc * inner * S + (S == 2 ? inter_off(4 * i, pc) : 4 * i)) = o;
   }
 }
 
@@ -697,70 +700,58 @@ extern "C" int gram_mask_key_bits(const uint8_t* mask, uint32_t* key_bits, int B
 
 extern "C" int gram_cross_attn_decode_split(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
                                             int B, int K, int H, int S, const int32_t* users, const int32_t* rowpos, int pieces,
-                                            int64_t q_pstride, int64_t bank_pstride, int64_t out_pstride, const uint32_t* key_bits,
-                                            void* stream) {
+                                            int64_t q_pstride, int64_t bank_pstride, const uint32_t* key_bits, void* stream) {
   if (B < 1 || K < 1 || K > GRAM_MAX_BEAMS || H < 1 || S < 32 || (S & 31) || S > 4096 || pieces < 1 || pieces > GRAM_MAX_PIECES ||
       (users == nullptr) != (rowpos == nullptr))
     return GRAM_E_ARG;
-  if (pieces > 1 && (q_pstride < 1 || bank_pstride < (int64_t)H * S * 64 || out_pstride < 1)) return GRAM_E_ARG;
+  if (pieces > 1 && (q_pstride < 1 || bank_pstride < (int64_t)H * S * 64)) return GRAM_E_ARG;
   if ((reinterpret_cast<uintptr_t>(mask) & 15) || (reinterpret_cast<uintptr_t>(k_layer) & 15) || (reinterpret_cast<uintptr_t>(vt_layer) & 15))
     return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   gram_prof::Scope prof(GRAM_K_CROSS_ATTN, st, 4.0 * B * H * S * 64 * pieces);  // K + V^T, bf16, every piece
-  switch (pieces) {
-    case 1: return launch_cross_nt<1>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, out_pstride, key_bits, st);
-    case 2: return launch_cross_nt<2>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, out_pstride, key_bits, st);
-    default: return launch_cross_nt<3>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, out_pstride, key_bits, st);
-  }
+  if (pieces == 2) return launch_cross_nt<2>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, key_bits, st);
+  return launch_cross_nt<1>(q, k_layer, vt_layer, mask, out, B, K, H, S, users, rowpos, q_pstride, bank_pstride, key_bits, st);
 }
 
 extern "C" int gram_cross_attn_decode(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
                                       int B, int K, int H, int S, void* stream) {
-  return gram_cross_attn_decode_split(q, k_layer, vt_layer, mask, out, B, K, H, S, nullptr, nullptr, 1, 0, 0, 0, nullptr, stream);
+  return gram_cross_attn_decode_split(q, k_layer, vt_layer, mask, out, B, K, H, S, nullptr, nullptr, 1, 0, 0, nullptr, stream);
 }
 
 extern "C" int gram_cross_attn_decode_live(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out,
                                            int n_users, const int32_t* users, const int32_t* rowpos, int K, int H, int S,
                                            void* stream) {
   if (!users || !rowpos) return GRAM_E_ARG;
-  return gram_cross_attn_decode_split(q, k_layer, vt_layer, mask, out, n_users, K, H, S, users, rowpos, 1, 0, 0, 0, nullptr, stream);
+  return gram_cross_attn_decode_split(q, k_layer, vt_layer, mask, out, n_users, K, H, S, users, rowpos, 1, 0, 0, nullptr, stream);
 }
 
 extern "C" int gram_dec_self_attn_split(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias, void* out,
                                         int R, int n_rows, const int32_t* rows, int H, int t, int Tmax, int pieces,
-                                        int64_t qkv_pstride, int64_t cache_pstride, int64_t out_pstride, void* stream) {
+                                        int64_t qkv_pstride, int64_t cache_pstride, void* stream) {
   if (R < 1 || n_rows < 1 || n_rows > R || H < 1 || H > 16 || t < 0 || t >= Tmax || Tmax > GRAM_MAX_DEC_LEN || pieces < 1 ||
       pieces > GRAM_MAX_PIECES)
     return GRAM_E_ARG;
-  if (pieces > 1 && (qkv_pstride < 1 || cache_pstride < (int64_t)Tmax * R * H * 64 || out_pstride < 1)) return GRAM_E_ARG;
+  if (pieces > 1 && (qkv_pstride < 1 || cache_pstride < (int64_t)Tmax * R * H * 64)) return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   gram_prof::Scope prof(GRAM_K_DEC_SELF_ATTN, st, 4.0 * n_rows * H * 64 * (t + 1) * pieces);
   const dim3 grid(n_rows), block(H * 16);
-  switch (pieces) {
-    case 1:
-      hipLaunchKernelGGL(dec_self_attn_kernel<1>, grid, block, 0, st, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, anc, bias,
-                         (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride, (long)out_pstride);
-      break;
-    case 2:
-      hipLaunchKernelGGL(dec_self_attn_kernel<2>, grid, block, 0, st, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, anc, bias,
-                         (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride, (long)out_pstride);
-      break;
-    default:
-      hipLaunchKernelGGL(dec_self_attn_kernel<3>, grid, block, 0, st, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, anc, bias,
-                         (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride, (long)out_pstride);
-      break;
-  }
+  if (pieces == 2)
+    hipLaunchKernelGGL(dec_self_attn_kernel<2>, grid, block, 0, st, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, anc, bias,
+                       (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride);
+  else
+    hipLaunchKernelGGL(dec_self_attn_kernel<1>, grid, block, 0, st, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, anc, bias,
+                       (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int gram_dec_self_attn(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias, void* out,
                                   int R, int H, int t, int Tmax, void* stream) {
-  return gram_dec_self_attn_split(qkv, kcache, vcache, anc, bias, out, R, R, nullptr, H, t, Tmax, 1, 0, 0, 0, stream);
+  return gram_dec_self_attn_split(qkv, kcache, vcache, anc, bias, out, R, R, nullptr, H, t, Tmax, 1, 0, 0, stream);
 }
 
 extern "C" int gram_dec_self_attn_live(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias,
                                        void* out, int R, int n_rows, const int32_t* rows, int H, int t, int Tmax, void* stream) {
   if (!rows) return GRAM_E_ARG;
-  return gram_dec_self_attn_split(qkv, kcache, vcache, anc, bias, out, R, n_rows, rows, H, t, Tmax, 1, 0, 0, 0, stream);
+  return gram_dec_self_attn_split(qkv, kcache, vcache, anc, bias, out, R, n_rows, rows, H, t, Tmax, 1, 0, 0, stream);
 }

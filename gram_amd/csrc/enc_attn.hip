@@ -19,10 +19,10 @@ namespace {
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int vtswz(int d, int key) { return d * 256 + ((((key >> 3) ^ (d & 15))) << 4) + (key & 7) * 2; }
 
-template <int NKS, int S>  // L = 32 * NKS; S = bf16 pieces per value (1: plain bf16; 2, 3: gram_split_t)
+template <int NKS, int S>  // L = 32 * NKS; S = 16-bit pieces per value (1: plain; 2: gram_split_t -- q|k|v planar, the output interleaved)
 __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bias,
                                                        const uint8_t* __restrict__ mask, bf16* __restrict__ out, int H,
-                                                       long qkv_pstride, long out_pstride) {
+                                                       long qkv_pstride) {
   constexpr int L = 32 * NKS;
   using T = SplitTab<S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
     lt += __shfl_xor(lt, 32, 64);
     const float inv_l = 1.f / lt;
     const int query = q0 + 16 * nt + c;
-    bf16* orow = out + ((size_t)p * L + query) * inner + h * 64;
+    bf16* orow = out + ((size_t)p * L + query) * inner * S;  // (S == 2: the O GEMM's interleaved A operand, [rows][2 * inner])
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       f32x4 v = o[mt][nt] * inv_l;
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
           r[j] = (bf16)v[j];
           v[j] -= (float)r[j];
         }
-        *reinterpret_cast<bf16x4*>(orow + pc * out_pstride + 16 * mt + 4 * g) = r;
+        const int n = h * 64 + 16 * mt + 4 * g;
+        *reinterpret_cast<bf16x4*>(orow + (S == 2 ? inter_off(n, pc) : n)) = r;
       }
     }
   }
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
 
 template <int S>
 int launch_enc(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H, long qkv_pstride,
-               long out_pstride, hipStream_t st) {
+               hipStream_t st) {
   const dim3 grid(H, P), block(256);
   constexpr int smem = S * 2 * 128 * 128 + (256 + 128) * 4;
   static bool attr_set = false;
@@ -198,10 +199,10 @@ int launch_enc(const void* qkv, const float* bias, const uint8_t* mask, void* ou
     attr_set = true;
   }
   switch (L / 32) {
-    case 1: hipLaunchKernelGGL((enc_attn_kernel<1, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride, out_pstride); break;
-    case 2: hipLaunchKernelGGL((enc_attn_kernel<2, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride, out_pstride); break;
-    case 3: hipLaunchKernelGGL((enc_attn_kernel<3, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride, out_pstride); break;
-    default: hipLaunchKernelGGL((enc_attn_kernel<4, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride, out_pstride); break;
+    case 1: hipLaunchKernelGGL((enc_attn_kernel<1, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride); break;
+    case 2: hipLaunchKernelGGL((enc_attn_kernel<2, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride); break;
+    case 3: hipLaunchKernelGGL((enc_attn_kernel<3, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride); break;
+    default: hipLaunchKernelGGL((enc_attn_kernel<4, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride); break;
   }
   GRAM_CHECK_LAUNCH();
   return 0;
@@ -211,18 +212,15 @@ int launch_enc(const void* qkv, const float* bias, const uint8_t* mask, void* ou
 
 extern "C" int gram_enc_self_attn(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H,
                                   void* stream) {
-  return gram_enc_self_attn_split(qkv, bias, mask, out, P, L, H, 1, 0, 0, stream);
+  return gram_enc_self_attn_split(qkv, bias, mask, out, P, L, H, 1, 0, stream);
 }
 
 extern "C" int gram_enc_self_attn_split(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H,
-                                        int pieces, int64_t qkv_pstride, int64_t out_pstride, void* stream) {
+                                        int pieces, int64_t qkv_pstride, void* stream) {
   if (P < 1 || H < 1 || L < 32 || L > GRAM_MAX_PASSAGE_LEN || (L & 31) || pieces < 1 || pieces > GRAM_MAX_PIECES) return GRAM_E_ARG;
-  if (pieces > 1 && (qkv_pstride < (int64_t)P * L * 3 * H * 64 || out_pstride < (int64_t)P * L * H * 64)) return GRAM_E_ARG;
+  if (pieces > 1 && qkv_pstride < (int64_t)P * L * 3 * H * 64) return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  gram_prof::Scope prof(GRAM_K_ENC_ATTN, st, 4.0 * P * H * L * L * 64 * GRAM_SPLIT_NPROD[pieces]);
-  switch (pieces) {
-    case 1: return launch_enc<1>(qkv, bias, mask, out, P, L, H, qkv_pstride, out_pstride, st);
-    case 2: return launch_enc<2>(qkv, bias, mask, out, P, L, H, qkv_pstride, out_pstride, st);
-    default: return launch_enc<3>(qkv, bias, mask, out, P, L, H, qkv_pstride, out_pstride, st);
-  }
+  gram_prof::Scope prof(GRAM_K_ENC_ATTN, st, 4.0 * P * H * L * L * 64 * (pieces == 2 ? 3 : 1));
+  if (pieces == 2) return launch_enc<2>(qkv, bias, mask, out, P, L, H, qkv_pstride, st);
+  return launch_enc<1>(qkv, bias, mask, out, P, L, H, qkv_pstride, st);
 }

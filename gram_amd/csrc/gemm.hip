@@ -25,11 +25,11 @@
 //                      ring by LDS-DMA; bf16 / bf16+ReLU / fp32-residual epilogues (16-column sum-of-squares partials).
 //   gemm_skinny_kernel M <= 64: one 16-column n-tile per wave over the whole K, operands straight from global memory
 //                      (what is left on it: the lm_head of a small batch and producers of 64-column partials).
-//   gemm_reg2_kernel   registers -> LDS, 2 LDS stages, loads issued one k-tile ahead (the first correct kernel; kept as
-//                      variant 0 for cross-checks).
-// All of them take split-bf16 operands (gram_split_t / KSplit): the k-loop walks nprod chunks of K, chunk c reading A piece
-// GRAM_SPLIT_A_PIECE[c] (a pointer offset) against chunk c of the product-expanded W, and every bf16 result is written as
-// pieces.  The MFMA sequence per accumulator is the same in every kernel, so their outputs are bit-identical.
+// All of them take two-piece ("x3") operands as well (gram_split_t, template parameter X3): A and W are then INTERLEAVED matrices
+// [rows][K/32][piece 0: 32 columns | piece 1: 32 columns], i.e. a 64-column physical k-tile holds both pieces of one 32-column block
+// of K, fetched ONCE, and yields three MFMA products per fragment pair -- a0*w1, a1*w0, a0*w0, in this order, block after block --
+// instead of one product-major pass over K per product (round 2: every operand tile travelled L2 -> LDS -> registers once per
+// product).  The MFMA sequence per accumulator is the same in every kernel, so their outputs are bit-identical.
 // Workgroup ids are remapped XCD-aware (ids i and i+8 share an XCD and its 4 MiB L2): every
 // XCD walks a contiguous range of tiles.
 #include <stdlib.h>
@@ -43,10 +43,9 @@ namespace {
 #ifndef GRAM_PP_RES_NT
 #define GRAM_PP_RES_NT 0  // A/B build hook: the ping-pong kernel's residual read with the nt hint
 #endif
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+constexpr int BN = 128, BK = 64;
 
-enum { V_DMA_M64 = 31, V_REG2 = 0, V_DMA = 1, V_DMA_M256 = 3, V_PP = 22, V_RING_M64 = 33, V_RING_M128 = 34 };  // (ids kept from the variant table of round 1)
+enum { V_DMA_M64 = 31, V_DMA = 1, V_DMA_M256 = 3, V_PP = 22, V_RING_M64 = 33, V_RING_M128 = 34 };  // (ids kept from the variant table of round 1)
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
 int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain)
 
@@ -78,16 +77,16 @@ struct EpiArgs {
   // split-bf16 outputs (gram_split_t): every bf16 result (C of the bf16 epilogues, xb_out, the bank) is written as `split` pieces
   // p0 = bf16(v), p1 = bf16(v - p0), ...; piece p lives `*_pstride` elements after piece p - 1
   int split;
-  long c_pstride, xb_pstride, bank_pstride;
+  long c_pstride, bank_pstride;
+  // split == 2: xb_out is interleaved ([M][2 * ldc], a 32-column block's two pieces side by side: the next GEMM's A operand); a bf16
+  // C is interleaved too when c_inter != 0 (ldc is then its physical row stride, >= 2 N) and `c_pstride` apart otherwise (the
+  // attention kernels read planar pieces)
+  int c_inter;
+  // every result is acc * out_scale (gram_split_t.out_scale): the inverse of the power-of-two factor the caller scaled W by, so that
+  // the low pieces of small weights stay out of the f16 subnormal range.  A power of two (checked on the host): exact wherever it is
+  // applied, so every kernel may fold it where it is cheapest (into the row scale, into the residual add as an fma) -- same bits.
+  float out_scale;
 };
-// Split-bf16 reduction (gram_split_t): the k-loop runs over np chunks of nktc k-tiles; chunk c multiplies piece (amap >> 4c) & 15 of A
-// (the [M][lda] matrix a_pstride elements after piece 0's) with columns c * kc + k of the product-expanded W.  np = 1: the plain GEMM.
-struct KSplit {
-  int np, nktc, kc;
-  uint32_t amap;
-  long a_pstride;  // elements between the bf16 pieces of A
-};
-__device__ __forceinline__ long ks_acol(const KSplit& ks, int c) { return (long)((ks.amap >> (4 * c)) & 15u) * ks.a_pstride; }
 inline uint32_t magic_u32(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }
 __device__ __forceinline__ uint32_t udiv_magic(uint32_t x, uint32_t d, uint32_t mg) { return d <= 1 ? x : __umulhi(x, mg); }
 
@@ -117,9 +116,32 @@ __device__ __forceinline__ void tile_of_block(int ntn, int& mt, int& nt) {
 }
 
 // one k-tile of MFMAs from a staged LDS tile pair
-template <int TNW>
+template <int TNW, bool X3>
 __device__ __forceinline__ void compute_tile(const char* sa, const char* sw, int wm, int wn, int r16, int g,
                                              f32x4 (&acc)[TNW][4]) {
+  if constexpr (X3) {
+    // the tile's 64 physical columns = both pieces of one 32-column block of K (chunks 0..3: piece 0, chunks 4..7: piece 1):
+    // a0*w1, a1*w0, a0*w0 -- smallest first -- from ONE fetch of the four fragment sets
+    // (the A fragments of both pieces stay in registers, the W fragments come one n-tile at a time: 10 fragments live, not 16 --
+    // the single-stage instantiations run at 128 registers per lane; an accumulator meets its three products 4 MFMAs apart)
+    bf16x8 fa0[4], fa1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + r16, g));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa1[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + r16, 4 + g));
+#pragma unroll
+    for (int i = 0; i < TNW; ++i) {
+      const bf16x8 fw1 = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 16 * TNW + i * 16 + r16, 4 + g));
+      const bf16x8 fw0 = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 16 * TNW + i * 16 + r16, g));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw1, fa0[j], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw0, fa1[j], acc[i][j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw0, fa0[j], acc[i][j]);
+    }
+    return;
+  }
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     bf16x8 fw[TNW], fa[4];
@@ -157,7 +179,7 @@ __device__ __forceinline__ float row_rscale(const EpiArgs& ep, int m) {
 // dependent loads of the partials are hidden behind the main loop instead of stalling the epilogue.
 __device__ __forceinline__ void load_row_scales(const EpiArgs& ep, int mbase, int r16, int M, float (&rs4)[4]) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) rs4[j] = row_rscale(ep, min(mbase + j * 16 + r16, M - 1));
+  for (int j = 0; j < 4; ++j) rs4[j] = row_rscale(ep, min(mbase + j * 16 + r16, M - 1)) * ep.out_scale;
   // pin the values HERE: without this hipcc sinks the dependent loads down to their use in the epilogue
   // (registers are tight), where they stall every tile by ~3 us
   if (ep.ss_in) {
@@ -174,10 +196,16 @@ __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
 }
 __device__ __forceinline__ f32x4 unpack_bf16x4(uint2 u) {
   f32x4 r;
+#ifdef GRAM_F16
+  const bf16x4 h = __builtin_bit_cast(bf16x4, u);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = (float)h[e];
+#else
   r[0] = __uint_as_float(u.x << 16);
   r[1] = __uint_as_float(u.x & 0xffff0000u);
   r[2] = __uint_as_float(u.y << 16);
   r[3] = __uint_as_float(u.y & 0xffff0000u);
+#endif
   return r;
 }
 
@@ -210,7 +238,8 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
           recv.y = __shfl_xor(send.y, 16, 64);
           // even g: tile i, columns 8*(g/2)..+7 = [own lo | partner's lo]; odd g: tile i+1 = [partner's hi | own hi]
           const uint4 out = odd ? make_uint4(recv.x, recv.y, hi.x, hi.y) : make_uint4(lo.x, lo.y, recv.x, recv.y);
-          if (row_ok) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(ep.C) + pc * ep.c_pstride + (size_t)m * ep.ldc + n) = out;
+          bf16* dst = reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + (ep.c_inter ? inter_off(n, pc) : pc * ep.c_pstride + n);
+          if (row_ok) *reinterpret_cast<uint4*>(dst) = out;
           if (pc + 1 < ep.split) {
             v0 -= unpack_bf16x4(lo);
             v1 -= unpack_bf16x4(hi);
@@ -221,6 +250,8 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
       // logits + softmax partials of this wave's 64-column block (TNW == 4): a lane holds 16 of the
       // 64 values of row m (4 per n-tile), the other 48 sit in the lanes g^1, g^2, g^3 of the same r16
       static_assert(TNW == 4, "F32_LSE epilogue is written for 64-column wave tiles");
+#pragma unroll
+      for (int i = 0; i < TNW; ++i) acc[i][j] *= ep.out_scale;
       float mx = -INFINITY;
 #pragma unroll
       for (int i = 0; i < TNW; ++i)
@@ -257,7 +288,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
 #pragma unroll
       for (int i = 0; i < TNW; ++i) {
         const int n = n0 + wn * 16 * TNW + i * 16 + 4 * g;
-        f32x4 v = acc[i][j];
+        f32x4 v = acc[i][j] * ep.out_scale;
         if (row_ok) {
         if constexpr (EPI == GRAM_EPI_F32_ADD) {
           f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n);
@@ -265,9 +296,10 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
           *p = nv;
           if (ep.xb_out) {
             f32x4 rem = nv;
+            bf16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
             for (int pc = 0; pc < ep.split; ++pc) {
               const uint2 pk = pack_bf16x4(rem);
-              *reinterpret_cast<uint2*>(ep.xb_out + pc * ep.xb_pstride + (size_t)m * ep.ldc + n) = pk;
+              *reinterpret_cast<uint2*>(xrow + (ep.split == 2 ? inter_off(n, pc) : n)) = pk;
               rem -= unpack_bf16x4(pk);
             }
             ssq[i / 4] += (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
@@ -319,75 +351,6 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_reg2_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M,
-                                                           int N, int K, int lda, EpiArgs ep, KSplit ks) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;  // 2x2 waves
-  int mt, nt;
-  tile_of_block(N / BN, mt, nt);
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int r16 = lane & 15, g = lane >> 4;
-
-  // staging map: 4 passes, thread -> (row = tid>>3 + 32*i, chunk = tid&7)
-  const int srow = tid >> 3, schunk = tid & 7;
-  const bf16* a_src[4];
-  const bf16* w_src[4];
-  bool a_ok[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int row = srow + 32 * i;
-    a_ok[i] = (m0 + row) < M;
-    a_src[i] = A + (size_t)(a_ok[i] ? (m0 + row) : 0) * lda + schunk * 8;
-    w_src[i] = W + (size_t)(n0 + row) * K + schunk * 8;
-  }
-  bf16x8 ra[4], rw[4];
-  auto load_tile = [&](int kt) {
-    const int c = kt / ks.nktc;  // (np == 1: c = 0 and the A column is kt * BK)
-    const long acol = ks_acol(ks, c) + (kt - c * ks.nktc) * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = a_ok[i] ? ld_global_b128(a_src[i] + acol) : zero_bf16x8();
-      rw[i] = ld_global_b128(w_src[i] + kt * BK);
-    }
-  };
-  auto store_tile = [&](int stage) {
-    char* sa = smem + stage * 2 * TILE_BYTES;
-    char* sw = sa + TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int row = srow + 32 * i;
-      *reinterpret_cast<bf16x8*>(sa + swz(row, schunk)) = ra[i];
-      *reinterpret_cast<bf16x8*>(sw + swz(row, schunk)) = rw[i];
-    }
-  };
-
-  f32x4 acc[4][4];  // [n-tile][m-tile]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = K / BK;
-  float rs4[4];
-  load_row_scales(ep, m0 + wm * 64, r16, M, rs4);
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int stage = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
-    const char* sa = smem + stage * 2 * TILE_BYTES;
-    compute_tile<4>(sa, sa + TILE_BYTES, wm, wn, r16, g, acc);
-    if (kt + 1 < nkt) store_tile(stage ^ 1);
-    __syncthreads();
-  }
-  epilogue<EPI, 4>(acc, m0, n0, wm, wn, r16, g, M, ep, rs4);
-}
-
 // Row-contiguous fp32 epilogue for the 64x64 wave tiles of gemm_dma_kernel: the wave's accumulators go through a
 // 4-KiB LDS patch (the k-loop's stage is idle by then), 16 rows per pass, so the residual read-modify-write moves
 // whole 256-B row segments (and the bf16 copy whole 128-B lines) instead of 64-B / 32-B pieces.
@@ -413,7 +376,7 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 4 + (lane >> 4), c = lane & 15;
-      f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16));
+      f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16)) * ep.out_scale;
       const int m = m0 + wm * 64 + j * 16 + row;
       float ssq = 0.f;
       if (m < M) {
@@ -423,9 +386,11 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
         if constexpr (EPI == GRAM_EPI_F32_ADD) {
           if (ep.xb_out) {
             f32x4 rem = val;
+            bf16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
+            const int n = n0 + wn * 64 + c * 4;
             for (int pc = 0; pc < ep.split; ++pc) {
               const uint2 pk = pack_bf16x4(rem);
-              *reinterpret_cast<uint2*>(ep.xb_out + pc * ep.xb_pstride + (size_t)m * ep.ldc + n0 + wn * 64 + c * 4) = pk;
+              *reinterpret_cast<uint2*>(xrow + (ep.split == 2 ? inter_off(n, pc) : n)) = pk;
               rem -= unpack_bf16x4(pk);
             }
             ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
@@ -459,9 +424,9 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
 // the MFMA operand; A is a few KiB, L2-resident), 8 k-blocks of loads in flight.  The accumulators then meet in LDS and
 // wave 0 runs the common epilogue on the 64 x 64 tile, so every output bit equals the tiled kernels' (same MFMA
 // sequence per accumulator, same epilogue code).
-template <int EPI, int MT>  // MT = m-tiles of 16 rows per workgroup that exist (M <= 16 * MT, or MT = 4 and a grid row per 64 rows)
+template <int EPI, int MT, bool X3>  // MT = m-tiles of 16 rows per workgroup that exist (M <= 16 * MT, or MT = 4 and a grid row per 64 rows)
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                          int K, int lda, EpiArgs ep, KSplit ks) {
+                                                          int K, int lda, EpiArgs ep) {
   __shared__ f32x4 xch[4][MT][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
@@ -480,19 +445,28 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
   // U k-blocks (32 wide) of loads in flight, then their MFMAs (a second register set with the next loads already under
   // way was measured slower: 13.0 vs 11.4 ms of GEMM time per generate at B = 1)
   constexpr int U = 8;
-  const int nkb = ks.kc >> 5;  // k-blocks per chunk (one chunk = all of K unless the operands are split into bf16 pieces)
-  for (int c = 0; c < ks.np; ++c) {
-    const long acol = ks_acol(ks, c);
-    const int wcol = c * ks.kc;
-    for (int kb = 0; kb < nkb; kb += U) {
-      bf16x8 fw[U], fa[U][MT];
+  const int nkb = K >> 5;  // physical 32-column k-blocks (X3: an even/odd pair = piece 0 / piece 1 of one block of K)
+  for (int kb = 0; kb < nkb; kb += U) {
+    bf16x8 fw[U], fa[U][MT];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = min(kb + u, nkb - 1) << 5;  // (past the end: a valid re-read, not used)
-        fw[u] = ld_global_b128(wp + wcol + k);
+    for (int u = 0; u < U; ++u) {
+      const int k = min(kb + u, nkb - 1) << 5;  // (past the end: a valid re-read, not used)
+      fw[u] = ld_global_b128(wp + k);
 #pragma unroll
-        for (int j = 0; j < MT; ++j) fa[u][j] = a_ok[j] ? ld_global_b128(ap[j] + acol + k) : zero_bf16x8();
-      }
+      for (int j = 0; j < MT; ++j) fa[u][j] = a_ok[j] ? ld_global_b128(ap[j] + k) : zero_bf16x8();
+    }
+    if constexpr (X3) {
+#pragma unroll
+      for (int u = 0; u < U; u += 2)
+        if (kb + u < nkb) {  // a0*w1, a1*w0, a0*w0: the order of every kernel
+#pragma unroll
+          for (int j = 0; j < MT; ++j) acc1[j] = mfma16(fw[u + 1], fa[u][j], acc1[j]);
+#pragma unroll
+          for (int j = 0; j < MT; ++j) acc1[j] = mfma16(fw[u], fa[u + 1][j], acc1[j]);
+#pragma unroll
+          for (int j = 0; j < MT; ++j) acc1[j] = mfma16(fw[u], fa[u][j], acc1[j]);
+        }
+    } else {
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (kb + u < nkb) {
@@ -522,13 +496,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
   }
 }
 
-template <int EPI>
-int launch_skinny(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
-  if (M < 1 || N % 64 || K % 32 || (M + 63) / 64 > 65535) return GRAM_E_ARG;
+template <int EPI, bool X3>
+int launch_skinny(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+  if (M < 1 || N % 64 || K % (X3 ? 64 : 32) || (M + 63) / 64 > 65535) return GRAM_E_ARG;
   const dim3 grid(N / 64, (M + 63) / 64), block(256);
-  if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep, ks);
-  else if (M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep, ks);
-  else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep, ks);
+  if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1, X3>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
+  else if (M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2, X3>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4, X3>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -613,9 +587,9 @@ __device__ __forceinline__ float row_rscale_stream(const EpiArgs& ep, int m) {
   return rsqrtf(s * ep.inv_d + ep.eps);
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, bool X3>
 __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                          int K, int lda, int G, EpiArgs ep, KSplit ks) {
+                                                          int K, int lda, int G, EpiArgs ep) {
   static_assert(EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || EPI == GRAM_EPI_F32_ADD, "stream kernel epilogues");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NS = StreamCfg<MT>::NS, SB = StreamCfg<MT>::SB, Q = 1 + MT;
@@ -637,33 +611,26 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
 #pragma unroll
   for (int j = 0; j < MT; ++j) a_off[j] = (uint32_t)min(m0 + 16 * j + dr, M - 1) * (uint32_t)lda * 2u + (uint32_t)dch * 16u;
   const char* wsrc = reinterpret_cast<const char*>(W + (size_t)n0 * K);  // advances 256 B per issued stage
-  const char* abase = reinterpret_cast<const char*>(A);
+  const char* abase = reinterpret_cast<const char*>(A);  // advances 256 B per issued stage
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
-  const int nst = K >> 7;  // stages of 128 reduction columns (kc % 128 == 0: a stage never straddles two chunks)
-  int i_slot = 0, i_c = 0, i_kk = 0;  // cursor of the next stage to issue: ring slot, chunk, column inside the chunk
-  long i_acol = ks_acol(ks, 0);
+  const int nst = K >> 7;  // stages of 128 physical reduction columns (X3: both pieces of two 32-column blocks of K)
+  int i_slot = 0;          // ring slot of the next stage to issue
   auto issue = [&]() {
     const uint32_t dst = wave_lds + (uint32_t)i_slot * SB;
     dma16_asm(dst, w_off, wsrc);
-    const char* asrc = abase + (i_acol + i_kk) * 2;
 #pragma unroll
-    for (int j = 0; j < MT; ++j) dma16_asm(dst + 4096 * (1 + j), a_off[j], asrc);
+    for (int j = 0; j < MT; ++j) dma16_asm(dst + 4096 * (1 + j), a_off[j], abase);
     wsrc += 256;
+    abase += 256;
     i_slot = i_slot + 1 == NS ? 0 : i_slot + 1;
-    i_kk += 128;
-    if (i_kk == ks.kc) {
-      i_kk = 0;
-      ++i_c;
-      i_acol = ks_acol(ks, i_c);
-    }
   };
   const int npro = min(NS - 1, nst);
   for (int st = 0; st < npro; ++st) issue();
 
-  float rs = 1.f;
+  float rs = ep.out_scale;
   if constexpr (EPI != GRAM_EPI_F32_ADD) {
-    if (consumer && ep.ss_in) rs = row_rscale_stream(ep, min(m0 + wave * 16 + r16, M - 1));
+    if (consumer && ep.ss_in) rs = row_rscale_stream(ep, min(m0 + wave * 16 + r16, M - 1)) * ep.out_scale;
     asm volatile("" : "+v"(rs));  // (the partials' loads are waited for here, behind the first DMAs, not in the epilogue)
   }
 
@@ -685,8 +652,17 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
     c_slot = c_slot + 1 == NS ? 0 : c_slot + 1;
   };
   auto mfmas = [&](const bf16x8 (&fw)[4], const bf16x8 (&fa)[4]) {
+    if constexpr (X3) {
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) acc = mfma16(fw[kb], fa[kb], acc);
+      for (int kb = 0; kb < 4; kb += 2) {  // k-blocks (kb, kb + 1) = the two pieces of one block of K: a0*w1, a1*w0, a0*w0
+        acc = mfma16(fw[kb + 1], fa[kb], acc);
+        acc = mfma16(fw[kb], fa[kb + 1], acc);
+        acc = mfma16(fw[kb], fa[kb], acc);
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) acc = mfma16(fw[kb], fa[kb], acc);
+    }
   };
   // Stage st: wait for this wave's part of it, barrier (everyone's part has landed; stage st - 1 has been read: the barrier's
   // lgkmcnt(0)), read its fragments, refill the slot of stage st - 1, multiply stage st - 1 while the reads are in flight.
@@ -718,14 +694,15 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
     float ssq = 0.f;
     if (row_ok) {
       f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n);
-      f32x4 val = acc;
+      f32x4 val = acc * ep.out_scale;
       val += *pc;
       *pc = val;
       if (ep.xb_out) {
         f32x4 rem = val;
+        bf16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
         for (int p = 0; p < ep.split; ++p) {
           const uint2 pk = pack_bf16x4(rem);
-          *reinterpret_cast<uint2*>(ep.xb_out + p * ep.xb_pstride + (size_t)m * ep.ldc + n) = pk;
+          *reinterpret_cast<uint2*>(xrow + (ep.split == 2 ? inter_off(n, p) : n)) = pk;
           rem -= unpack_bf16x4(pk);
         }
         ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
@@ -744,13 +721,14 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
     }
     for (int p = 0; p < ep.split; ++p) {
       const uint2 pk = pack_bf16x4(v);
-      if (row_ok) *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(ep.C) + p * ep.c_pstride + (size_t)m * ep.ldc + n) = pk;
+      if (row_ok)
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + (ep.c_inter ? inter_off(n, p) : p * ep.c_pstride + n)) = pk;
       if (p + 1 < ep.split) v -= unpack_bf16x4(pk);
     }
   }
 }
 
-constexpr int kStreamMaxMLimit = 4096;  // (the callers size their quarter-partial buffers for this many rows)
+constexpr int kStreamMaxMLimit = GRAM_STREAM_MAX_M_LIMIT;  // (the callers size their quarter-partial buffers for this many rows)
 int stream_max_m() {  // rows up to which the streaming kernel is used; 0 = off (GRAM_GEMM_STREAM_MAXM: A/B hook)
   static const int v = [] {
     const char* e = getenv("GRAM_GEMM_STREAM_MAXM");
@@ -761,35 +739,35 @@ int stream_max_m() {  // rows up to which the streaming kernel is used; 0 = off 
 }
 bool stream_enabled() { return stream_max_m() > 0; }
 
-template <int EPI, int MT>
-int launch_stream_mt(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
+template <int EPI, int MT, bool X3>
+int launch_stream_mt(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
   constexpr int smem = StreamCfg<MT>::NS * StreamCfg<MT>::SB;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, MT, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int G = (M + 16 * MT - 1) / (16 * MT);
-  hipLaunchKernelGGL((gemm_stream_kernel<EPI, MT>), dim3((N / 16) * G), dim3(256), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, G, ep, ks);
+  hipLaunchKernelGGL((gemm_stream_kernel<EPI, MT, X3>), dim3((N / 16) * G), dim3(256), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, G, ep);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
 
 // rows per workgroup: as few as keep the launch within one workgroup per CU (more workgroups = more W in flight)
-template <int EPI>
-int launch_stream(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
-  if (M < 1 || M > kStreamMaxMLimit || N % 128 || ks.kc % 128) return GRAM_E_ARG;
+template <int EPI, bool X3>
+int launch_stream(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+  if (M < 1 || M > kStreamMaxMLimit || N % 128 || K % 128) return GRAM_E_ARG;
   const int nt = N / 16;
-  if (nt * ((M + 15) / 16) <= 256) return launch_stream_mt<EPI, 1>(A, W, M, N, K, lda, ep, ks, st);
-  if (nt * ((M + 31) / 32) <= 256) return launch_stream_mt<EPI, 2>(A, W, M, N, K, lda, ep, ks, st);
-  return launch_stream_mt<EPI, 4>(A, W, M, N, K, lda, ep, ks, st);
+  if (nt * ((M + 15) / 16) <= 256) return launch_stream_mt<EPI, 1, X3>(A, W, M, N, K, lda, ep, st);
+  if (nt * ((M + 31) / 32) <= 256) return launch_stream_mt<EPI, 2, X3>(A, W, M, N, K, lda, ep, st);
+  return launch_stream_mt<EPI, 4, X3>(A, W, M, N, K, lda, ep, st);
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int WM, int NST, int TNW>
-__global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 ? 4 : 2))) void gemm_dma_kernel(
-    const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks) {
+template <int EPI, int WM, int NST, int TNW, bool X3>
+__global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 ? (X3 ? 3 : 4) : 2))) void gemm_dma_kernel(
+    const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, int lda, EpiArgs ep) {
   // WM x 2 waves, block tile (64*WM) x 128.  NST = 1: single LDS stage, latency hidden by the other
   // resident workgroups.  NST = 2: the DMA of k-tile kt+1 is issued before the MFMAs of k-tile kt and
   // drained by the (single) barrier after them.
@@ -827,11 +805,9 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
   auto dma = [&](int kt, int stage) {
     char* sa = smem + stage * STAGE;
     char* sw = sa + A_BYTES;
-    const int c = kt / ks.nktc;  // (np == 1: c = 0 and the A column is kt * BK)
-    const long acol = ks_acol(ks, c) + (kt - c * ks.nktc) * BK;
 #pragma unroll
     for (int i = 0; i < AG; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + acol),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * BK),
                                        (__attribute__((address_space(3))) void*)(sa + (wave * AG + i) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < WG; ++i)
@@ -868,11 +844,10 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    int i_slot = 0, i_c = 0, i_kk = 0, i_kt = 0;  // cursor of the next k-tile to issue
-    long i_acol = ks_acol(ks, 0);
+    int i_slot = 0, i_kt = 0;  // cursor of the next k-tile to issue
     auto issue = [&]() {
       const uint32_t sa = lds0 + (uint32_t)i_slot * STAGE, sw = sa + A_BYTES;
-      const char* asrc = abase + (i_acol + i_kk) * 2;
+      const char* asrc = abase + (size_t)i_kt * (BK * 2);
       const char* wsrc = wbase + (size_t)i_kt * (BK * 2);
 #pragma unroll
       for (int i = 0; i < AG; ++i) dma16_asm(sa + (uwave * AG + i) * 1024, a_off[i], asrc);
@@ -880,12 +855,6 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
       for (int i = 0; i < WG; ++i) dma16_asm(sw + (uwave * WG + i) * 1024, w_off[i], wsrc);
       ++i_kt;
       i_slot = i_slot + 1 == NST ? 0 : i_slot + 1;
-      i_kk += BK;
-      if (i_kk == ks.kc) {
-        i_kk = 0;
-        ++i_c;
-        i_acol = ks_acol(ks, i_c);
-      }
     };
     const int npro = min(NST - 1, nkt);
     for (int kt = 0; kt < npro; ++kt) issue();
@@ -895,7 +864,7 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
       wait_later<Q>(min(NST - 2, nkt - 1 - kt));
       __syncthreads();
       if (kt + NST - 1 < nkt) issue();
-      compute_tile<TNW>(smem + c_slot * STAGE, smem + c_slot * STAGE + A_BYTES, wm, wn, r16, g, acc);
+      compute_tile<TNW, X3>(smem + c_slot * STAGE, smem + c_slot * STAGE + A_BYTES, wm, wn, r16, g, acc);
       c_slot = c_slot + 1 == NST ? 0 : c_slot + 1;
     }
     __syncthreads();  // (the row-contiguous epilogue re-uses the ring as its patches)
@@ -905,7 +874,7 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
     for (int kt = 0; kt < nkt; ++kt) {
       dma(kt, 0);
       __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
-      compute_tile<TNW>(smem, smem + A_BYTES, wm, wn, r16, g, acc);
+      compute_tile<TNW, X3>(smem, smem + A_BYTES, wm, wn, r16, g, acc);
       __syncthreads();
     }
   } else {
@@ -914,7 +883,7 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
     for (int kt = 0; kt < nkt; ++kt) {
       const int st = kt & 1;
       if (kt + 1 < nkt) dma(kt + 1, st ^ 1);
-      compute_tile<TNW>(smem + st * STAGE, smem + st * STAGE + A_BYTES, wm, wn, r16, g, acc);
+      compute_tile<TNW, X3>(smem + st * STAGE, smem + st * STAGE + A_BYTES, wm, wn, r16, g, acc);
       __syncthreads();  // drains DMA(kt+1) and fences the reads of stage st
     }
   }
@@ -969,11 +938,13 @@ struct PPOut {
   uint32_t ldx_b;   // ldc * 2
   uint32_t ss_nblk;
   int rows;
-  int split;            // bf16 pieces written (gram_split_t); piece p is c_ps_b / xb_ps_b bytes after piece p - 1
-  long c_ps_b, xb_ps_b;
+  int split;            // bf16 pieces written (gram_split_t)
+  long c_ps_b;          // planar bf16 C: piece p is c_ps_b bytes after piece p - 1
+  bool inter;           // bf16 C interleaved (c = C + (m_first * ldc + 2 * n_first) * 2, ldc_b the physical row stride); xb always is when split == 2
   bool nt;              // streaming (nt) stores for the bf16 rows (A/B hook GRAM_GEMM_NT7)
+  float scale;          // EpiArgs.out_scale
 };
-template <int EPI, bool FULL, int SMODE = 0>
+template <int EPI, bool FULL>
 __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, char* patch, const PPOut& o, int lane_, const float* rs) {
   // opaque copy of the lane id: keeps hipcc from hoisting every store address of the tile out of the k-loop
   // (loop-invariant, 2 VGPRs each) and spilling them -- a scratch reload inside a load slot is a vmcnt(0) drain
@@ -985,7 +956,7 @@ __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, c
     const int j = j0 + jj;
     if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU) {
       // 16 rows x 64 cols bf16: patch[16][128 B], chunk c (16 B) at c ^ (row & 7); one pass per bf16 piece of the output
-      const float sc = rs ? rs[j * 16 + r16] : 1.f;
+      const float sc = (rs ? rs[j * 16 + r16] : 1.f) * o.scale;
       f32x4 v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1009,11 +980,9 @@ __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, c
           const int row = it * 8 + (lane >> 3), c = lane & 7;
           const uint4 val = *reinterpret_cast<const uint4*>(patch + row * 128 + ((c ^ (row & 7)) * 16));
           const int mr = j * 16 + row;
-          if constexpr (SMODE == 1) {
-            asm volatile("" ::"v"(val.x), "v"(val.y), "v"(val.z), "v"(val.w));
-          } else {
-            if (FULL || mr < o.rows) store16(o.c + pc * o.c_ps_b + ((uint32_t)mr * o.ldc_b + c * 16), val, o.nt);
-          }
+          // planar: the piece's 128-B row segment; interleaved: its two 64-B halves, side by side with the other piece's
+          const uint32_t coff = o.inter ? (uint32_t)((c >> 2) * 128 + pc * 64 + (c & 3) * 16) : (uint32_t)(c * 16);
+          if (FULL || mr < o.rows) store16(o.c + (o.inter ? 0 : pc * o.c_ps_b) + ((uint32_t)mr * o.ldc_b + coff), val, o.nt);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -1028,7 +997,7 @@ __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, c
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = it * 4 + (lane >> 4), c = lane & 15;
-        f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16));
+        f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16)) * o.scale;
         const int mr = j * 16 + row;
         float ssq = 0.f;
         if (FULL || mr < o.rows) {
@@ -1094,7 +1063,7 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int row = it * 4 + (lane >> 4), c = lane & 15;
-        f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16));
+        f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16)) * o.scale;
         const int mr = j * 16 + row;
         float ssq = 0.f;
         if (mr < o.rows) {
@@ -1106,7 +1075,9 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
               f32x4 rem = val;
               for (int pc = 0; pc < o.split; ++pc) {
                 const uint2 pk = pack_bf16x4(rem);
-                *reinterpret_cast<uint2*>(o.xb + pc * o.xb_ps_b + ((uint32_t)mr * o.ldx_b + c * 8)) = pk;
+                // (split == 2: interleaved -- lanes 0..7 hold block 0 of the wave's 64 columns, lanes 8..15 block 1)
+                const uint32_t xoff = o.split == 2 ? (uint32_t)((c >> 3) * 128 + pc * 64 + (c & 7) * 8) : (uint32_t)(c * 8);
+                *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + xoff)) = pk;
                 rem -= unpack_bf16x4(pk);
               }
               ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
@@ -1135,15 +1106,15 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
 
 // full: all 128 rows of the wave exist (no per-row predicates: the stores of a pass issue back to back and
 // their number is exact, which the counted DMA waits of the following slots rely on)
-template <int EPI, int SMODE = 0>
+template <int EPI>
 __device__ __forceinline__ void pp_store_rows(f32x4 (&acc)[4][8], int j0, char* patch, const PPOut& o, int lane, const float* rs) {
-  if (o.rows >= 128) pp_store_rows_impl<EPI, true, SMODE>(acc, j0, patch, o, lane, rs);
-  else pp_store_rows_impl<EPI, false, SMODE>(acc, j0, patch, o, lane, rs);
+  if (o.rows >= 128) pp_store_rows_impl<EPI, true>(acc, j0, patch, o, lane, rs);
+  else pp_store_rows_impl<EPI, false>(acc, j0, patch, o, lane, rs);
 }
 
-template <int EPI, int ABL = 0>
+template <int EPI, bool X3 = false>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                         int K, int lda, EpiArgs ep, int ntiles, int stagger, KSplit ks) {
+                                                         int K, int lda, EpiArgs ep, int ntiles, int stagger) {
   constexpr int TB = 256, HT = 16384;
   constexpr bool F32OUT = EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD;
   constexpr bool KV = EPI == PP_KV_K || EPI == PP_KV_V;  // n-tiles of the K blocks only / of the V blocks only
@@ -1151,13 +1122,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // epilogue patches: fp32 outputs 8 x 4 KiB (one per wave, used in load slots); bf16 outputs 4 x 4 KiB, shared by
   // waves w and w+4 -- the two groups use them in alternate time slots (each inside its own MFMA slot)
   constexpr int PATCH = 4096;
-  // TEND: the epilogue runs at the end of the tile, both wave groups in step (fp32 outputs).  ABL 7 = the same for bf16
-  // outputs (microbench variant 27): 1 035 vs 1 105 TFLOP/s for the in-slot jobs on the encoder QKV shape, so bf16 stays in-slot
   constexpr bool LSE = EPI == GRAM_EPI_F32_LSE;  // lm_head in sparse mode: only the (max, sum exp) partials leave the kernel
-  // ABL 7 also serves the split-bf16 modes: their bf16 / bank outputs are several pieces per value (a store count the in-slot
-  // jobs' counted waits do not cover), and with a 3x / 6x longer k-loop the tile-end placement costs little
-  constexpr bool TEND = (EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD) || LSE || ABL == 7;
-  constexpr bool SPLIT = ABL == 7;  // every split-operand GEMM runs on an ABL 7 instantiation: the plain kernels carry none of its state
+  // X3 = the two-piece kernel: interleaved operands (a k-tile's 128-B rows hold piece 0 | piece 1 of one 32-column block of K),
+  // 24 MFMAs per quadrant slot instead of 16 (a0*w1, a1*w0, a0*w0 from the SAME fragment registers).
+  // TEND: the epilogue runs at the end of the tile, both wave groups in step: fp32 outputs (a read-modify-write needs its residual
+  // loads out of the DMA queue's way) and every X3 output (two pieces per value: a store count the in-slot jobs' counted waits do
+  // not cover; with 1.5x the MFMAs per k-tile the tile-end placement costs less than it does in the plain kernel, where in-slot
+  // bf16 stores measured 1 105 vs 1 035 TFLOP/s on the encoder QKV shape)
+  constexpr bool TEND = (EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD) || LSE || X3;
   constexpr int RS_OFF = 8 * HT + 4 * 4096;  // bf16 epilogues: 2 x 1 KiB of row scales behind the patches
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 8 half-tile buffers + epilogue patches (+ row scales)
   const int tid = threadIdx.x;
@@ -1205,9 +1177,6 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // DMA cursor = stream k-tile kk+2 (tile, kt) + per-lane byte offsets of this wave's 2 pieces of each half-tile type
   // (relative to the tile's first A row / W row, whose addresses c_A / c_W are wave-uniform and 64-bit)
   int c_tile = slot, c_kt = 0;
-  // split-bf16 operands (KSplit): k-tile c_kin of chunk c_chunk; the chunk's A piece starts c_aoff bytes after piece 0
-  int c_kin = 0, c_chunk = 0;
-  long c_aoff = SPLIT ? ks_acol(ks, 0) * 2 : 0;
   // W offsets never change (H2 = H1 + 32 rows goes into the uniform base); A offsets change only for the M-tail tile
   const char *c_A, *c_W;
   uint32_t offA[2][2], offW[2], offW2[LSE ? 2 : 1];  // LSE: W rows clamped per tile (the last n-tile may be half empty)
@@ -1243,28 +1212,17 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     }
   };
   auto advance = [&]() {
-    if constexpr (SPLIT) {
-      if (++c_kin == ks.nktc) {
-        c_kin = 0;
-        ++c_chunk;
-        c_aoff = ks_acol(ks, c_chunk) * 2;
-      }
-    }
     if (++c_kt == nkt) {
       c_kt = 0;
-      if constexpr (SPLIT) {
-        c_chunk = 0;
-        c_aoff = ks_acol(ks, 0) * 2;
-      }
       if (c_tile + G < ntiles) c_tile += G;  // past the end of the stream: fetch this tile again (harmless, keeps the counts uniform)
       set_offsets();
     }
   };
   auto issue = [&](int t, int par) {  // this wave's 2 DMA instructions of half-tile (cursor, type t) -> buffer (par, t)
-    if constexpr (ABL != 2) {
+    {
       const uint32_t dst = wave_lds + (par * 4 + t) * HT;
       if (t == 0 || t == 3) {
-        const char* base = SPLIT ? c_A + c_aoff + c_kin * (BK * 2) : c_A + c_kt * (BK * 2);
+        const char* base = c_A + c_kt * (BK * 2);
         dma16_asm(dst, offA[t == 3][0], base);
         dma16_asm(dst + 1024, offA[t == 3][1], base);
       } else {
@@ -1288,7 +1246,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   const char* const a_base[2] = {smem + swz(wr * 64 + r16, g), smem + swz(wr * 64 + r16, 4 + g)};
   const char* const w_base[2] = {smem + swz(wc * 32 + r16, g), smem + swz(wc * 32 + r16, 4 + g)};
   auto read_a = [&](int par, int mq) {
-    if constexpr (ABL != 5) {
+    {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1297,7 +1255,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     }
   };
   auto read_w = [&](int par, int nq) {
-    if constexpr (ABL != 5) {
+    {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1307,24 +1265,25 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   };
   // TR (KV bank, V^T half): operands the other way round, so a lane ends up with 4 consecutive ROWS (bank
   // positions s) of one column d -- the V^T layout -- instead of 4 consecutive columns of one row
+  constexpr int NMQ = X3 ? 24 : 16;  // MFMAs of a quadrant slot
   auto mfma_q = [&](auto TRc, int mq, int nq, int n) {
-    const int ks = n >> 3, i = (n >> 2) & 1, j = n & 3;
+    // plain: k-steps 0, 1 of the k-tile.  X3: the "k-steps" are the two PIECES of one block of K (fa[p], fw[nq][p]) and the slot
+    // issues a0*w1, a1*w0, a0*w0 -- every accumulator meets its three products 8 MFMAs apart
+    const int pr = n >> 3, i = (n >> 2) & 1, j = n & 3;
+    const int ka = X3 ? (pr == 1 ? 1 : 0) : pr, kw = X3 ? (pr == 0 ? 1 : 0) : pr;
     f32x4& c = acc[nq * 2 + i][mq * 4 + j];
-    if constexpr (decltype(TRc)::value) c = mfma16(fa[ks][j], fw[nq][ks][i], c);
-    else c = mfma16(fw[nq][ks][i], fa[ks][j], c);
+    if constexpr (decltype(TRc)::value) c = mfma16(fa[ka][j], fw[nq][kw][i], c);
+    else c = mfma16(fw[nq][kw][i], fa[ka][j], c);
   };
   auto mma = [&](int mq, int nq, auto TRc) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (ABL != 1) {
 #pragma unroll
-      for (int n = 0; n < 16; ++n) mfma_q(TRc, mq, nq, n);
-    }
+    for (int n = 0; n < NMQ; ++n) mfma_q(TRc, mq, nq, n);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     pp_barrier();
   };
-  constexpr bool STORES = ABL != 3 && ABL != 5;
   // bf16 epilogues: an MFMA slot that also stores the 32 finished rows of m-tiles J0, J0+1 (not the quadrant being
   // computed).  Scale/convert/ds_write pieces fill the issue gaps of the first 8 MFMAs, the patch reads those of
   // the next 4, and the 4 row-contiguous global stores go out behind the last MFMA, so the slot is barely longer.
@@ -1334,10 +1293,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     int ln = lane;
     asm volatile("" : "+v"(ln));  // opaque: no hoisting of the addresses below out of the k-loop (they would be spilled)
     const int lr = ln & 15, lg = ln >> 4;
-    float sc[2] = {1.f, 1.f};
+    float sc[2] = {o.scale, o.scale};
     if (rs) {
-      sc[0] = rs[J0 * 16 + lr];
-      sc[1] = rs[J0 * 16 + 16 + lr];
+      sc[0] = rs[J0 * 16 + lr] * o.scale;
+      sc[1] = rs[J0 * 16 + 16 + lr] * o.scale;
     }
     uint4 pva;
     // register-lean addressing: one per-lane base each for the patch writes, the patch reads and the stores
@@ -1352,23 +1311,19 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     const uint32_t voff0 = (uint32_t)mr0 * o.ldc_b + (ln & 7) * 16;
     auto get = [&](int it) { return *reinterpret_cast<const uint4*>(gbase + it * 1024); };
     auto put = [&](int it, const uint4& v) {  // -> its 128-B segment of C
-      if constexpr (ABL == 6) {
-        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-      } else {
-        if (FULL || mr0 + it * 8 < o.rows) {
-          uint4* dst = reinterpret_cast<uint4*>(o.c + (voff0 + (uint32_t)(it * 8) * o.ldc_b));
-          // streaming (nt) store: the output is far larger than L2 and is next read by another kernel; keeping it
-          // out of L2 leaves the A panels this XCD re-reads there (measured +1.6 ... 4 %)
-          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-          __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst));
-        }
+      if (FULL || mr0 + it * 8 < o.rows) {
+        uint4* dst = reinterpret_cast<uint4*>(o.c + (voff0 + (uint32_t)(it * 8) * o.ldc_b));
+        // streaming (nt) store: the output is far larger than L2 and is next read by another kernel; keeping it
+        // out of L2 leaves the A panels this XCD re-reads there (measured +1.6 ... 4 %)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(dst));
       }
     };
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
-      if constexpr (ABL != 1) mfma_q(TRc, mq, nq, n);
+      mfma_q(TRc, mq, nq, n);
       if (n < 8 && (n & 1)) {
 #pragma unroll
         for (int pc = n - 1; pc <= n; ++pc) {  // piece pc: m-tile J0 + (pc >> 2), n-tile pc & 3
@@ -1435,7 +1390,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // (wave-uniform base + 32-bit per-lane offset)
   auto kv_direct = [&](auto TRc, const KVLoc& q, int jj, int pi, const f32x4& v, int lr, int lg) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 pk = __builtin_bit_cast(u32x2, pack_bf16x4(v));
+    const u32x2 pk = __builtin_bit_cast(u32x2, pack_bf16x4(v * ep.out_scale));
     if constexpr (decltype(TRc)::value) {  // lane: column d = pi*16 + lr, rows s0 + jj*16 + 4*lg .. +3
       const uint32_t off = ((uint32_t)(pi * 16 + lr) * 32u + jj * 16 + 4 * lg) * 2u;
       if (q.mblk + jj * 16 + 4 * lg < M) __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(q.vb + off));
@@ -1472,13 +1427,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
-      if constexpr (ABL != 1) mfma_q(TRc, mq, nq, n);
+      mfma_q(TRc, mq, nq, n);
       if (n < 8 && (n & 1)) {
 #pragma unroll
         for (int pc = n - 1; pc <= n; ++pc) {
           const int jj = pc >> 2, pi = pc & 3;
           const int chunk = (jj * 2 + (lg >> 1)) ^ wsw;
-          *reinterpret_cast<uint2*>(const_cast<char*>(wbase) + pi * 1024 + chunk * 16) = pack_bf16x4(acc[pi][J0 + jj]);
+          *reinterpret_cast<uint2*>(const_cast<char*>(wbase) + pi * 1024 + chunk * 16) = pack_bf16x4(acc[pi][J0 + jj] * ep.out_scale);
         }
       }
       if (n == 7) __builtin_amdgcn_wave_barrier();
@@ -1510,7 +1465,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     o.ldc_b = 128;
     o.rows = M - (tm0 + wr * 128);
     o.split = 1;
+    o.inter = false;
     o.nt = true;  // (the bank is next read by another kernel, much later)
+    o.scale = ep.out_scale;
     return o;
   };
   // extra = number of epilogue stores this wave has issued since the DMA that must have landed (a lower bound is
@@ -1568,17 +1525,19 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     PPOut o;
     const size_t mf = (size_t)tm0 + wr * 128;
     const int nf = tn0 + wc * 64;
-    o.c = reinterpret_cast<char*>(ep.C) + (mf * ep.ldc + nf) * ESZ;
-    o.xb = ep.xb_out ? reinterpret_cast<char*>(ep.xb_out) + (mf * ep.ldc + nf) * 2 : nullptr;
+    o.inter = !F32OUT && ep.c_inter != 0;
+    o.c = reinterpret_cast<char*>(ep.C) + (mf * ep.ldc + (o.inter ? 2 * nf : nf)) * ESZ;
+    // (split == 2: xb is interleaved, [M][2 * ldc])
+    o.xb = ep.xb_out ? reinterpret_cast<char*>(ep.xb_out) + (mf * ep.ldc + nf) * 2 * ep.split : nullptr;
     o.ss = ep.ss_out ? ep.ss_out + mf * ep.ss_out_nblk + (nf >> 6) : nullptr;
     o.ldc_b = ep.ldc * ESZ;
-    o.ldx_b = ep.ldc * 2;
+    o.ldx_b = ep.ldc * 2 * ep.split;
     o.ss_nblk = ep.ss_out_nblk;
     o.rows = M - (int)mf;
     o.split = ep.split;
     o.c_ps_b = ep.c_pstride * 2;
-    o.xb_ps_b = ep.xb_pstride * 2;
     o.nt = (ep.nt & 8) != 0;
+    o.scale = ep.out_scale;
     return o;
   };
   // one MFMA slot of quadrant (mq, nq), optionally with the epilogue job "store m-tiles J0, J0+1 of tile (tm0, tn0)"
@@ -1620,12 +1579,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       const bool first = kt == 0, last = kt + 2 >= nkt;
       // bf16 epilogues of FULL tiles issue exactly 4 stores per store slot (the slots p2, p3 of a tile's last k-tile
       // and p0, p1 of the next tile's first): pf / lf = such stores were / are issued around this k-tile pair
-      const bool pf = !TEND && !F32OUT && !KV && STORES && first && pending && M - (pm0 + wr * 128) >= 128;
-      const bool lf = !TEND && !F32OUT && !KV && STORES && last && M - (m0 + wr * 128) >= 128;
+      const bool pf = !TEND && !F32OUT && !KV && first && pending && M - (pm0 + wr * 128) >= 128;
+      const bool lf = !TEND && !F32OUT && !KV && last && M - (m0 + wr * 128) >= 128;
       // ================= even k-tile (buffers 0): n order 0, 1
       // Epilogue of the previous tile's m1 half (m-tiles 4..7, finished by its last MFMA slot): fp32 outputs store it
       // in the load slots of p0 / p1, bf16 outputs inside the MFMA slots of p0 / p1 (which compute m0 quadrants).
-      const bool st_prev = STORES && first && pending, st_cur = STORES && last;
+      const bool st_prev = first && pending, st_cur = last;
       read_a(0, 0);
       issue(1, 0);  // W_n0(kk+2)
       end_load_slot(pf ? 8 : 0);
@@ -1674,7 +1633,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       advance();
     }
     const bool more = tile + G < ntiles;
-    if constexpr (TEND && STORES) {
+    if constexpr (TEND) {
       // fp32 outputs: the read-modify-write epilogue runs at the END of the tile with both wave groups in step (like the
       // 256x128-tile kernel): inside the slots its residual loads drain the in-order DMA queue four times per tile and
       // group; here once.  Group 0 waits for group 1's last MFMA slot, both store, and group 1 falls one barrier behind again.
@@ -1686,6 +1645,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
         if (blk < ep.lse_nblk) {  // (the padding half of the last n-tile has no block)
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] *= ep.out_scale;
             float mx = -INFINITY;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -1727,6 +1688,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
               const char* const gbase = kvpatch + rd * 64 + ((rc ^ ((rd >> 2) & 3)) * 16);
               const uint32_t voff0 = ((uint32_t)rd * 32u + rc * 8) * 2u;
               char* vb = q.vb;
+#pragma unroll
+              for (int pcs = 0; pcs < 8; ++pcs) acc[pcs & 3][J0 + (pcs >> 2)] *= ep.out_scale;
               for (int pc = 0; pc < ep.split; ++pc) {
 #pragma unroll
                 for (int pcs = 0; pcs < 8; ++pcs) {
@@ -1755,10 +1718,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       if constexpr (F32OUT) {
         pp_store_tile_f32<EPI>(acc, patch, o, lane);
       } else {
-        pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 0, patch, o, lane, rs_cur);
-        pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 2, patch, o, lane, rs_cur);
-        pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, patch, o, lane, rs_cur);
-        pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, patch, o, lane, rs_cur);
+        pp_store_rows<EPI>(acc, 0, patch, o, lane, rs_cur);
+        pp_store_rows<EPI>(acc, 2, patch, o, lane, rs_cur);
+        pp_store_rows<EPI>(acc, 4, patch, o, lane, rs_cur);
+        pp_store_rows<EPI>(acc, 6, patch, o, lane, rs_cur);
       }
       }
       zero_half(0);
@@ -1775,21 +1738,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   }
   // The last tile's m1 half is still in the accumulators.  Every DMA of this workgroup must have landed before it
   // ends, and after that the half-tile buffers are dead: they serve as 8 private patches for the final stores.
-  if constexpr (!(TEND && STORES)) {
+  if constexpr (!TEND) {
     if (wr == 0) pp_barrier();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   pp_barrier();
-  if constexpr (TEND && STORES) {
-    // (stored at the end of every tile)
-  } else if constexpr (!STORES) {
-    float keep = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (keep == 123.456f) reinterpret_cast<float*>(ep.C)[0] = keep;
-  } else {
+  if constexpr (!TEND) {  // (TEND: stored at the end of every tile)
     const float* rs_prev = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128 : nullptr;
     if constexpr (KV) {
 #pragma unroll
@@ -1803,19 +1757,19 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       }
     } else {
       const PPOut o = make_out(pm0, pn0);
-      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 4, smem + wave * 4096, o, lane, rs_prev);
-      pp_store_rows<EPI, (ABL == 6 ? 1 : 0)>(acc, 6, smem + wave * 4096, o, lane, rs_prev);
+      pp_store_rows<EPI>(acc, 4, smem + wave * 4096, o, lane, rs_prev);
+      pp_store_rows<EPI>(acc, 6, smem + wave * 4096, o, lane, rs_prev);
     }
   }
 }
 
-template <int EPI, int ABL = 0>
-int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
+template <int EPI, bool X3 = false>
+int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
   if constexpr (EPI == GRAM_EPI_KV_BANK) {  // the public id: both halves, one launch each (no kernel of its own)
-    const int r = launch_pp<PP_KV_K, ABL>(A, W, M, N, K, lda, ep, ks, st);
-    return r ? r : launch_pp<PP_KV_V, ABL>(A, W, M, N, K, lda, ep, ks, st);
+    const int r = launch_pp<PP_KV_K, X3>(A, W, M, N, K, lda, ep, st);
+    return r ? r : launch_pp<PP_KV_V, X3>(A, W, M, N, K, lda, ep, st);
   } else {
-  if (ks.np > 1 && ABL != 7) return GRAM_E_ARG;
+  if ((ep.split > 1) != X3) return GRAM_E_ARG;
   constexpr int smem = 8 * 16384 + 8 * 4096;  // 160 KiB
   if ((EPI == GRAM_EPI_F32_LSE ? N % 128 : N % 256) || (K / BK) % 2 || K / BK < 4 || (ep.ss_in && ep.ss_nblk != 0)) return GRAM_E_ARG;
   if (EPI == GRAM_EPI_F32_LSE && ep.C) return GRAM_E_ARG;  // dense logits: the 128-row kernels
@@ -1841,7 +1795,7 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     const int nblocks = ntiles < n_cu ? ntiles : n_cu;
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<EPI, ABL>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<EPI, X3>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       if (e != hipSuccess) return (int)e;
       attr_set = true;
@@ -1851,17 +1805,17 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     // split operands (K' = 3K / 6K: panels three / six times the size), same box, GEMM ms per step: groups of 2: 1 097, 3: 1 100, 4: 1 088,
     // 5: 1 098, 6: 1 097, 8: 1 091, 12: 1 101 -- 4 x 8 = the 32 tiles an XCD runs at a time
     static const int gm_set = getenv("GRAM_GEMM_GROUPM") ? atoi(getenv("GRAM_GEMM_GROUPM")) : -1;  // A/B hook (0/1: n fastest)
-    const int gm_env = gm_set >= 0 ? gm_set : (ks.np > 1 ? 4 : 6);
+    const int gm_env = gm_set >= 0 ? gm_set : (ep.split > 1 ? 4 : 6);
     const int ntn_ = ntiles / ((M + 255) / 256);
     const int gm = ntn_ >= 8 && gm_env > 1 && gm_env < 256 ? gm_env : 0;
-    // Tile-end epilogues (ABL 7: the split-operand modes) leave every CU storing at the same moment when all workgroups run in step:
+    // Tile-end epilogues (the two-piece kernel) leave every CU storing at the same moment when all workgroups run in step:
     // a start stagger spreads the bursts over the tile period (GRAM_GEMM_STAGGER, A/B hook; see gemm_pp_kernel)
     static const int nt7 = getenv("GRAM_GEMM_NT7") ? atoi(getenv("GRAM_GEMM_NT7")) : 0;  // A/B hook: streaming stores of the tile-end bf16 rows (measured: no gain)
     if (nt7) ep.nt |= 8;
     static const int stagger_env = getenv("GRAM_GEMM_STAGGER") ? atoi(getenv("GRAM_GEMM_STAGGER")) : -1;
     const int stagger = stagger_env >= 0 ? stagger_env : g_stagger;
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, ABL>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda,
-                       ep, ntiles, (stagger & 0xffff) | (gm << 16), ks);
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, X3>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda,
+                       ep, ntiles, (stagger & 0xffff) | (gm << 16));
     GRAM_CHECK_LAUNCH();
     return 0;
   }
@@ -1891,61 +1845,61 @@ int pick_variant(int M, int N, int K) {
   return V_DMA;
 }
 
-template <int EPI, int WM, int NST, int TNW = 4>
-int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
+template <int EPI, int WM, int NST, bool X3, int TNW = 4>
+int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
   constexpr int TBM = 64 * WM, TBN = 32 * TNW;
   constexpr int smem = NST * (TBM + TBN) * BK * 2;
   if (N % TBN) return GRAM_E_ARG;
   const int nblocks = (N / TBN) * ((M + TBM - 1) / TBM);
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<EPI, WM, NST, TNW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<EPI, WM, NST, TNW, X3>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   static const int rows_env = getenv("GRAM_GEMM_DMAROWS") ? atoi(getenv("GRAM_GEMM_DMAROWS")) : 1;  // A/B hook; measured +1.2 % end to end
   if (rows_env) ep.nt |= 4;
-  hipLaunchKernelGGL((gemm_dma_kernel<EPI, WM, NST, TNW>), dim3(nblocks), dim3(WM * 128), smem, st, (const bf16*)A, (const bf16*)W,
-                     M, N, K, lda, ep, ks);
+  hipLaunchKernelGGL((gemm_dma_kernel<EPI, WM, NST, TNW, X3>), dim3(nblocks), dim3(WM * 128), smem, st, (const bf16*)A, (const bf16*)W,
+                     M, N, K, lda, ep);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
 
 constexpr int V_SKINNY = 30, V_STREAM = 32;
 
-template <int EPI>
-int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, KSplit ks, hipStream_t st) {
-  gram_prof::Scope prof(GRAM_K_GEMM, st, 2.0 * M * N * K);  // K = the executed reduction length (np * kc for split operands)
+template <int EPI, bool X3>
+int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
+  gram_prof::Scope prof(GRAM_K_GEMM, st, (X3 ? 3.0 : 2.0) * M * N * K);  // EXECUTED MFMA flops: K = physical columns; X3: 3 products per 2 of them
   if constexpr (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || EPI == GRAM_EPI_F32_ADD) {
     // one user (or a few): the streaming kernel.  A producer of 64-column sum-of-squares partials stays on the older skinny kernel.
-    const bool fits = M <= stream_max_m() && N % 128 == 0 && ks.kc % 128 == 0 && (EPI != GRAM_EPI_F32_ADD || !ep.ss_out || ep.ss_quarter);
-    if (g_force_variant == V_STREAM || (g_force_variant < 0 && stream_enabled() && fits)) return launch_stream<EPI>(A, W, M, N, K, lda, ep, ks, st);
+    const bool fits = M <= stream_max_m() && N % 128 == 0 && K % 128 == 0 && (EPI != GRAM_EPI_F32_ADD || !ep.ss_out || ep.ss_quarter);
+    if (g_force_variant == V_STREAM || (g_force_variant < 0 && stream_enabled() && fits)) return launch_stream<EPI, X3>(A, W, M, N, K, lda, ep, st);
   }
   if (ep.ss_quarter) return GRAM_E_ARG;  // (only the streaming kernel reads / writes that layout)
   if constexpr (EPI != GRAM_EPI_KV_BANK) {
     static const int use_skinny = getenv("GRAM_GEMM_SKINNY") ? atoi(getenv("GRAM_GEMM_SKINNY")) : 1;  // A/B hook
     static const int skinny_max_m = getenv("GRAM_GEMM_SKINNY_MAXM") ? atoi(getenv("GRAM_GEMM_SKINNY_MAXM")) : 64;  // A/B hook
-    if (g_force_variant == V_SKINNY || (g_force_variant < 0 && use_skinny && M <= skinny_max_m && N % 64 == 0 && K % 32 == 0))
-      return launch_skinny<EPI>(A, W, M, N, K, lda, ep, ks, st);
+    if (g_force_variant == V_SKINNY || (g_force_variant < 0 && use_skinny && M <= skinny_max_m && N % 64 == 0 && K % 64 == 0))
+      return launch_skinny<EPI, X3>(A, W, M, N, K, lda, ep, st);
   }
   // The ping-pong kernel declines shapes it does not cover (GRAM_E_ARG); those run on the 256x128 tiles.
   // GRAM_GEMM_PP=0 (A/B hook) keeps it out altogether.
   static const int use_pp = getenv("GRAM_GEMM_PP") ? atoi(getenv("GRAM_GEMM_PP")) : 1;
   const bool pp_ok = use_pp != 0;
-  // split operands: bf16 / bank results leave the ping-pong kernel at the tile end (its ABL 7 instantiation)
-  auto pp = [&]() { return ks.np > 1 ? launch_pp<EPI, 7>(A, W, M, N, K, lda, ep, ks, st) : launch_pp<EPI>(A, W, M, N, K, lda, ep, ks, st); };
+  // (two-piece operands: the ping-pong kernel's X3 instantiation; its results leave at the tile end)
+  auto pp = [&]() { return launch_pp<EPI, X3>(A, W, M, N, K, lda, ep, st); };
   if constexpr (EPI == GRAM_EPI_F32_LSE) {  // 64-column wave tiles only: the ping-pong kernel (partials only) or the 128-row kernels
     if ((g_force_variant == V_PP || (g_force_variant < 0 && pp_ok && M >= 32768)) && !ep.C) {
       const int r = pp();
       if (r != GRAM_E_ARG) return r;
     }
     const int pv = pick_variant(M, N, K);
-    return pv == V_RING_M64    ? launch_dma<EPI, 1, 6>(A, W, M, N, K, lda, ep, ks, st)
-           : pv == V_RING_M128 ? launch_dma<EPI, 2, 4>(A, W, M, N, K, lda, ep, ks, st)
-           : pv == V_DMA_M64   ? launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, ks, st)
-           : pv == V_DMA   ? launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, ks, st)
-                           : launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, ks, st);
+    return pv == V_RING_M64    ? launch_dma<EPI, 1, 6, X3>(A, W, M, N, K, lda, ep, st)
+           : pv == V_RING_M128 ? launch_dma<EPI, 2, 4, X3>(A, W, M, N, K, lda, ep, st)
+           : pv == V_DMA_M64   ? launch_dma<EPI, 1, 1, X3>(A, W, M, N, K, lda, ep, st)
+           : pv == V_DMA   ? launch_dma<EPI, 2, 1, X3>(A, W, M, N, K, lda, ep, st)
+                           : launch_dma<EPI, 4, 1, X3>(A, W, M, N, K, lda, ep, st);
   } else {
   if constexpr (EPI == GRAM_EPI_F32_ADD) {  // big-M residual GEMMs: the ping-pong kernel with its tile-end epilogue, whatever N and K
     if (g_force_variant < 0 && pp_ok && M >= 32768) {
@@ -1954,31 +1908,18 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
     }
   }
   switch (pick_variant(M, N, K)) {
-    case V_DMA: return launch_dma<EPI, 2, 1>(A, W, M, N, K, lda, ep, ks, st);
-    case V_DMA_M64: return launch_dma<EPI, 1, 1>(A, W, M, N, K, lda, ep, ks, st);
-    case V_RING_M64: return launch_dma<EPI, 1, 6>(A, W, M, N, K, lda, ep, ks, st);
-    case V_RING_M128: return launch_dma<EPI, 2, 4>(A, W, M, N, K, lda, ep, ks, st);
+    case V_DMA_M64: return launch_dma<EPI, 1, 1, X3>(A, W, M, N, K, lda, ep, st);
+    case V_RING_M64: return launch_dma<EPI, 1, 6, X3>(A, W, M, N, K, lda, ep, st);
+    case V_RING_M128: return launch_dma<EPI, 2, 4, X3>(A, W, M, N, K, lda, ep, st);
     case V_PP:
       if (g_force_variant == V_PP || pp_ok) {
         const int r = pp();
         if (r != GRAM_E_ARG || g_force_variant == V_PP) return r;
       }
       [[fallthrough]];
-    case V_DMA_M256: return launch_dma<EPI, 4, 1>(A, W, M, N, K, lda, ep, ks, st);
-    default: break;
+    case V_DMA_M256: return launch_dma<EPI, 4, 1, X3>(A, W, M, N, K, lda, ep, st);
+    default: return launch_dma<EPI, 2, 1, X3>(A, W, M, N, K, lda, ep, st);  // V_DMA: 128 x 128 tiles
   }
-  const int nblocks = (N / BN) * ((M + BM - 1) / BM);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_reg2_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_reg2_kernel<EPI>, dim3(nblocks), dim3(256), 4 * TILE_BYTES, st, (const bf16*)A, (const bf16*)W, M, N,
-                     K, lda, ep, ks);
-  GRAM_CHECK_LAUNCH();
-  return 0;
   }
 }
 
@@ -1996,37 +1937,37 @@ extern "C" int gram_debug_set_gemm_variant(int v) {
 }
 
 namespace {
-// host side of gram_split_t: the chunk -> A piece map of the kernels (products smallest first, see gram_hip.h)
-int make_ksplit(const gram_split_t* sp, int kc, KSplit& ks, EpiArgs& ep) {
+// host side of gram_split_t
+int make_split(const gram_split_t* sp, EpiArgs& ep) {
   const int pieces = sp ? sp->pieces : 1;
-  if (pieces < 1 || pieces > GRAM_MAX_PIECES || kc % BK) return GRAM_E_ARG;
-  ks.np = GRAM_SPLIT_NPROD[pieces];
-  ks.kc = kc;
-  ks.nktc = kc / BK;
-  ks.amap = 0;
-  for (int c = 0; c < ks.np; ++c) ks.amap |= (uint32_t)GRAM_SPLIT_A_PIECE[pieces][c] << (4 * c);
-  ks.a_pstride = sp ? sp->a_pstride : 0;
+  if (pieces < 1 || pieces > GRAM_MAX_PIECES) return GRAM_E_ARG;
   ep.split = pieces;
   ep.c_pstride = sp ? sp->c_pstride : 0;
-  ep.xb_pstride = sp ? sp->xb_pstride : 0;
   ep.bank_pstride = sp ? sp->bank_pstride : 0;
-  if (pieces > 1 && ks.a_pstride < 1) return GRAM_E_ARG;
+  ep.c_inter = sp && pieces == 2 && sp->c_interleaved != 0;
+  ep.out_scale = sp && sp->out_scale != 0.f ? sp->out_scale : 1.f;
+  int ex = 0;
+  if (!(ep.out_scale > 0.f) || frexpf(ep.out_scale, &ex) != 0.5f) return GRAM_E_ARG;  // a power of two: exact wherever it is applied
   return 0;
+}
+template <int EPI>
+int launch_p(const void* A, const void* W, int M, int N, int K, int lda, const EpiArgs& ep, hipStream_t st) {
+  return ep.split == 2 ? launch<EPI, true>(A, W, M, N, K, lda, ep, st) : launch<EPI, false>(A, W, M, N, K, lda, ep, st);
 }
 }  // namespace
 
 extern "C" int gram_gemm_bf16_lse_split(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int kc, int lda,
                                         int ldc, const gram_split_t* split, void* stream) {
-  if (M < 1 || N % BN != 0 || kc % BK != 0 || lda < kc || (lda & 7) || !lse_part || (logits && (ldc & 3))) return GRAM_E_ARG;
   EpiArgs ep{};
-  KSplit ks{};
-  const int r = make_ksplit(split, kc, ks, ep);
+  const int r = make_split(split, ep);
   if (r) return r;
+  const int K = ep.split * kc;  // physical reduction length: W is [N][K], A [M][lda >= K]; two pieces: interleaved by 32-column blocks
+  if (M < 1 || N % BN != 0 || kc % BK != 0 || lda < K || (lda & 7) || !lse_part || (logits && (ldc & 3))) return GRAM_E_ARG;
   ep.C = logits;
   ep.ldc = ldc;
   ep.lse_part = lse_part;
   ep.lse_nblk = N / 64;
-  return launch<GRAM_EPI_F32_LSE>(A, W, M, N, ks.np * kc, lda, ep, ks, (hipStream_t)stream);
+  return launch_p<GRAM_EPI_F32_LSE>(A, W, M, N, K, lda, ep, (hipStream_t)stream);
 }
 
 extern "C" int gram_gemm_bf16_lse(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int K, int lda,
@@ -2047,19 +1988,18 @@ extern "C" int gram_gemm_bf16_ex(const void* A, const void* W, void* C, int M, i
 extern "C" int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M, int N, int kc, int lda, int ldc, int epilogue,
                                     const gram_kv_bank_t* bank, const gram_norm_fusion_t* nf, const gram_split_t* split,
                                     void* stream) {
-  if (M < 1 || N % BN != 0 || kc % BK != 0 || lda < kc || (lda & 7)) return GRAM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   EpiArgs ep{};
-  KSplit ks{};
   {
-    const int r = make_ksplit(split, kc, ks, ep);
+    const int r = make_split(split, ep);
     if (r) return r;
   }
-  const int K = ks.np * kc;  // executed reduction length; W is [N][K]
+  const int K = ep.split * kc;  // physical reduction length (see gram_gemm_bf16_lse_split)
+  if (M < 1 || N % BN != 0 || kc % BK != 0 || lda < K || (lda & 7)) return GRAM_E_ARG;
   if (ep.split > 1) {
     const bool bf16_out = epilogue == GRAM_EPI_BF16 || epilogue == GRAM_EPI_BF16_RELU;
-    if ((bf16_out && ep.c_pstride < 1) || (epilogue == GRAM_EPI_KV_BANK && ep.bank_pstride < 1) ||
-        (epilogue == GRAM_EPI_F32_ADD && nf && nf->xb_out && ep.xb_pstride < 1))
+    if ((bf16_out && !ep.c_inter && ep.c_pstride < 1) || (bf16_out && ep.c_inter && ldc < 2 * N) ||
+        (epilogue == GRAM_EPI_KV_BANK && ep.bank_pstride < 1))
       return GRAM_E_ARG;
   }
   ep.C = C;
@@ -2085,16 +2025,16 @@ extern "C" int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M
   switch (epilogue) {
     case GRAM_EPI_BF16:
       if (!C || (ldc & 7)) return GRAM_E_ARG;  // 16-byte row-aligned bf16 stores
-      return launch<GRAM_EPI_BF16>(A, W, M, N, K, lda, ep, ks, st);
+      return launch_p<GRAM_EPI_BF16>(A, W, M, N, K, lda, ep, st);
     case GRAM_EPI_BF16_RELU:
       if (!C || (ldc & 7)) return GRAM_E_ARG;
-      return launch<GRAM_EPI_BF16_RELU>(A, W, M, N, K, lda, ep, ks, st);
+      return launch_p<GRAM_EPI_BF16_RELU>(A, W, M, N, K, lda, ep, st);
     case GRAM_EPI_F32_ADD:
       if (!C || (ldc & 3)) return GRAM_E_ARG;
-      return launch<GRAM_EPI_F32_ADD>(A, W, M, N, K, lda, ep, ks, st);
+      return launch_p<GRAM_EPI_F32_ADD>(A, W, M, N, K, lda, ep, st);
     case GRAM_EPI_F32:
       if (!C || (ldc & 3)) return GRAM_E_ARG;
-      return launch<GRAM_EPI_F32>(A, W, M, N, K, lda, ep, ks, st);
+      return launch_p<GRAM_EPI_F32>(A, W, M, N, K, lda, ep, st);
     case GRAM_EPI_KV_BANK: {
       if (!bank || !bank->k || !bank->vt) return GRAM_E_ARG;
       const int inner = bank->H * 64;
@@ -2113,7 +2053,7 @@ extern "C" int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M
       ep.pmap = bank->passage_map;
       ep.pL = bank->L;
       ep.pN = bank->N;
-      return launch<GRAM_EPI_KV_BANK>(A, W, M, N, K, lda, ep, ks, st);
+      return launch_p<GRAM_EPI_KV_BANK>(A, W, M, N, K, lda, ep, st);
     }
     default:
       return GRAM_E_ARG;

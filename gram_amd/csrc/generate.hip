@@ -23,7 +23,9 @@ struct GraphEntry {
   float lp;
   const void *ws, *t_off, *t_tok, *t_node;
   int t_nodes, t_edges, t_fan, t_min;
-  hipGraphExec_t exec;  // nullptr: shape seen once (run eagerly, so that every lazy one-time initialisation has happened)
+  hipGraphExec_t exec;  // nullptr: shape seen once (run eagerly -- the SAME launch train the capture records, live-row compaction
+                        // off -- so that every lazy one-time initialisation of those kernels has happened outside the capture)
+  bool failed;          // a capture / instantiation failed once: this shape stays on eager launches
 };
 
 struct gram_model {
@@ -33,6 +35,9 @@ struct gram_model {
   gram_model_desc_t d;
   std::vector<const float*> enc_ln1, enc_ln2, dec_ln1, dec_ln2, dec_ln3;
   std::vector<const void*> enc_wqkv, enc_wo, enc_wi, enc_wo2, dec_wqkv, dec_wo, dec_wq_x, dec_wo_x, dec_wi, dec_wo2;
+  // 1 / (power-of-two factor a weight matrix was scaled by) = the out_scale of its GEMM (gram_model_desc_t.w_scales)
+  std::vector<float> s_enc_wqkv, s_enc_wo, s_enc_wi, s_enc_wo2, s_dec_wqkv, s_dec_wo, s_dec_wq_x, s_dec_wo_x, s_dec_wi, s_dec_wo2;
+  float s_wkv = 1.f, s_lm = 1.f;
 };
 
 namespace {
@@ -52,7 +57,15 @@ struct Carve {
 
 constexpr int64_t kGraphMaxRows = 4096;  // B*K up to which generate() is replayed from a HIP graph (GRAM_GRAPH=0: never)
 
-constexpr int kQuarterRows = 4096;  // >= gram_gemm_stream_max_m() always: rows up to which the sum-of-squares buffers hold 16-column partials
+// The folded-norm partial sums of squares are [rows][d / 64] floats, or -- "quarter" layout of the streaming small-M GEMM, chosen per
+// CALL from the rows that call works on (all of them, the compacted encoder rows, the live rows of a late decode step) --
+// [rows_of_the_call][d / 16] with rows_of_the_call <= gram_gemm_stream_max_m() <= kStreamRowsLimit.  The buffer holds the larger of
+// the two for every count the full row number allows, whatever GRAM_GEMM_STREAM_MAXM says.
+constexpr int64_t kStreamRowsLimit = GRAM_STREAM_MAX_M_LIMIT;  // (common.h: gram_gemm_stream_max_m() never exceeds it)
+inline int64_t ss_floats(int64_t rows, int64_t d) {
+  const int64_t q = (rows < kStreamRowsLimit ? rows : kStreamRowsLimit) * (d / 16), full = rows * (d / 64);
+  return q > full ? q : full;
+}
 struct Workspace {
   // encoder
   float* x;         // [Me][d]   residual stream (fp32)
@@ -90,9 +103,10 @@ struct Workspace {
   int64_t* seq_stage;    // [B*K][Tmax]
   float* score_stage;    // [B*K]
   int64_t bytes;
-  // split-bf16 modes (gram_split_t): every bf16 buffer above is `pieces` copies, these many elements apart
+  // two-piece mode (gram_split_t): what a GEMM reads (h, attn, u, hd, attnd, ud) is ONE interleaved buffer of twice the row length;
+  // what only attention kernels read (qkv, the bank, qkvd, qx, the cache) is `pieces` planar copies, these many elements apart
   int pieces;
-  int64_t ps_h, ps_qkv, ps_attn, ps_u, ps_bank, ps_hd, ps_qkvd, ps_attnd, ps_qx, ps_ud, ps_cache;
+  int64_t ps_qkv, ps_bank, ps_qkvd, ps_qx, ps_cache;
 };
 
 Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int Tmax) {
@@ -103,33 +117,27 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   Workspace w{};
   const int64_t P = c.pieces > 1 ? c.pieces : 1;
   w.pieces = (int)P;
-  w.ps_h = Me * d;
   w.ps_qkv = Me * 3 * inner;
-  w.ps_attn = Me * inner;
-  w.ps_u = Me * F;
   w.ps_bank = nl * B * c.n_heads * S * 64;
-  w.ps_hd = R * d;
   w.ps_qkvd = R * 3 * inner;
-  w.ps_attnd = R * inner;
   w.ps_qx = R * inner;
-  w.ps_ud = R * F;
   w.ps_cache = nl * Tmax * R * inner;
   w.x = cv.take<float>(Me * d);
-  w.h = cv.take<bf16>(P * w.ps_h);
+  w.h = cv.take<bf16>(P * Me * d);
   w.qkv = cv.take<bf16>(P * w.ps_qkv);
-  w.attn = cv.take<bf16>(P * w.ps_attn);
-  w.u = cv.take<bf16>(P * w.ps_u);
-  w.ss = cv.take<float>(Me <= kQuarterRows ? Me * (d / 16) : Me * (d / 64));
+  w.attn = cv.take<bf16>(P * Me * inner);
+  w.u = cv.take<bf16>(P * Me * F);
+  w.ss = cv.take<float>(ss_floats(Me, d));
   w.rs = cv.take<float>(Me);
   w.bank_k = cv.take<bf16>(P * w.ps_bank);
   w.bank_vt = cv.take<bf16>(P * w.ps_bank);
   w.xd = cv.take<float>(R * d);
-  w.hd = cv.take<bf16>(P * w.ps_hd);
+  w.hd = cv.take<bf16>(P * R * d);
   w.qkvd = cv.take<bf16>(P * w.ps_qkvd);
-  w.attnd = cv.take<bf16>(P * w.ps_attnd);
+  w.attnd = cv.take<bf16>(P * R * inner);
   w.qx = cv.take<bf16>(P * w.ps_qx);
-  w.ud = cv.take<bf16>(P * w.ps_ud);
-  w.ssd = cv.take<float>(R <= kQuarterRows ? R * (d / 16) : R * (d / 64));  // (16-column partials for a small-M step: gram_norm_fusion_t.quarter)
+  w.ud = cv.take<bf16>(P * R * F);
+  w.ssd = cv.take<float>(ss_floats(R, d));  // (16-column partials for a small-M step: gram_norm_fusion_t.quarter)
   w.rsd = cv.take<float>(R);
   w.kcache = cv.take<bf16>(P * w.ps_cache);
   w.vcache = cv.take<bf16>(P * w.ps_cache);
@@ -188,26 +196,32 @@ constexpr int kPrecomputedRsRows = 32768;  // = the row count from which gemm.hi
   } while (0)
 
 // Sensitivity sweeps (gram_debug_set_stage_pieces): stage s computes on its first g_stage_cap[s] pieces only.  Implemented by ZEROING
-// the upper pieces of the stage's activation operands before they are consumed (a zero piece contributes exact zeros to every product
-// it enters, so the arithmetic is that of the smaller piece count; the kernels and their cost are unchanged) -- the weights' upper
-// pieces are zeroed by the caller when it expands them.  Debug only: every cap costs a memset per use.
+// the upper piece of the stage's activation operands before they are consumed (a zero piece contributes exact zeros to every product
+// it enters, so the arithmetic is that of one piece; the kernels and their cost are unchanged) -- the weights' upper piece is
+// zeroed by the caller when it expands them.  Debug only: every cap costs a memset per use.
 int g_stage_cap[GRAM_STAGE_COUNT] = {99, 99, 99, 99, 99, 99, 99, 99};
-int cap_pieces(const Workspace& w, void* buf, int64_t ps, int stage, void* st);
-
-// One Linear of the path on (possibly split) operands: A (pieces a_ps apart) x W (product-expanded when pieces > 1);
-// c_ps = piece stride of whatever bf16 result the epilogue writes (C, xb_out or the bank).
-int linear(const Workspace& w, const void* A, int64_t a_ps, const void* W, void* C, int64_t c_ps, int M, int N, int kc, int lda, int ldc,
-           int epi, const gram_kv_bank_t* bank, const gram_norm_fusion_t* nf, void* st) {
-  const gram_split_t sp{w.pieces, a_ps, c_ps, c_ps, c_ps};
-  return gram_gemm_bf16_split(A, W, C, M, N, kc, lda, ldc, epi, bank, nf, &sp, st);
+// planar buffer: `pieces` copies, ps elements apart
+int cap_planar(const Workspace& w, void* buf, int64_t ps, int stage, void* st) {
+  if (w.pieces < 2 || g_stage_cap[stage] >= 2) return 0;
+  hipError_t e = hipMemsetAsync((bf16*)buf + (size_t)ps, 0, (size_t)ps * sizeof(bf16), (hipStream_t)st);
+  return e == hipSuccess ? 0 : (int)e;
+}
+// interleaved buffer [rows][cols / 32][2][32]: piece 1 = the second 64 B of every 128 B
+int cap_inter(const Workspace& w, void* buf, int64_t rows, int64_t cols, int stage, void* st) {
+  if (w.pieces < 2 || g_stage_cap[stage] >= 2) return 0;
+  hipError_t e = hipMemset2DAsync((char*)buf + 64, 128, 0, 64, (size_t)(rows * cols / 32), (hipStream_t)st);
+  return e == hipSuccess ? 0 : (int)e;
 }
 
-int cap_pieces(const Workspace& w, void* buf, int64_t ps, int stage, void* st) {
-  for (int p = g_stage_cap[stage] < 1 ? 1 : g_stage_cap[stage]; p < w.pieces; ++p) {
-    hipError_t e = hipMemsetAsync((bf16*)buf + (size_t)p * ps, 0, (size_t)ps * sizeof(bf16), (hipStream_t)st);
-    if (e != hipSuccess) return (int)e;
-  }
-  return 0;
+// One Linear of the path.  Two-piece mode: A is the interleaved [M][2 kc] buffer, W the interleaved weight; a 16-bit C is written
+// planar (c_kind 1: c_ps elements apart -- an attention kernel reads it) or interleaved (c_kind 2: [M][2 N], the next GEMM's A);
+// the xb copy of a residual epilogue (nf) is always interleaved, the bank planar.
+enum { C_NONE = 0, C_PLANAR = 1, C_INTER = 2 };
+int linear(const Workspace& w, const void* A, const void* W, float out_scale, void* C, int c_kind, int64_t c_ps, int M, int N, int kc, int epi,
+           const gram_kv_bank_t* bank, const gram_norm_fusion_t* nf, void* st) {
+  const int P = w.pieces;
+  const gram_split_t sp{P, c_kind == C_INTER, c_ps, w.ps_bank, out_scale};
+  return gram_gemm_bf16_split(A, W, C, M, N, kc, P * kc, c_kind == C_INTER ? P * N : N, epi, bank, nf, &sp, st);
 }
 
 // The encoder layers on P passages (ids/mask [P][L]); leaves the residual stream in w.x rows [0, P*L).
@@ -216,7 +230,7 @@ int encoder_layers(const gram_model* m, const Workspace& w, const int64_t* ids, 
   const int d = c.d_model, inner = c.n_heads * 64, F = c.d_ff, H = c.n_heads;
   const int Me = P * L;
   if (c.fold_norm) {
-    // T5LayerNorm folded into the GEMMs around it (gram_norm_fusion_t): w.h holds xb = bf16(x), w.ss the
+    // T5LayerNorm folded into the GEMMs around it (gram_norm_fusion_t): w.h holds xb = the 16-bit copy of x, w.ss the
     // per-row sum-of-squares partials; both are refreshed by every residual GEMM's epilogue
     // few rows (one short user): the streaming GEMM and its 16-column partials (gram_norm_fusion_t.quarter); the embedding writes 64-column ones
     const int quarter = Me <= gram_gemm_stream_max_m() && d % 128 == 0 && inner % 128 == 0 && F % 128 == 0;
@@ -228,32 +242,32 @@ int encoder_layers(const gram_model* m, const Workspace& w, const int64_t* ids, 
     const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rs, 0, d, c.eps}
                                               : gram_norm_fusion_t{nullptr, nullptr, w.ss, d / 64, d, c.eps, quarter};
     const gram_norm_fusion_t consume_embed{nullptr, nullptr, w.ss, d / 64, d, c.eps, 0};
-    TRY(gram_embed_ex_split(c.embed_f32, ids, 1, w.x, w.h, w.ss, d / 64, Me, d, w.pieces, w.ps_h, st));
+    TRY(gram_embed_ex_split(c.embed_f32, ids, 1, w.x, w.h, w.ss, d / 64, Me, d, w.pieces, st));
     for (int i = 0; i < c.n_enc_layers; ++i) {
       if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
-      TRY(cap_pieces(w, w.h, w.ps_h, GRAM_STAGE_ENC_ATTN, st));
-      TRY(linear(w, w.h, w.ps_h, m->enc_wqkv[i], w.qkv, w.ps_qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr,
+      TRY(cap_inter(w, w.h, Me, d, GRAM_STAGE_ENC_ATTN, st));
+      TRY(linear(w, w.h, m->enc_wqkv[i], m->s_enc_wqkv[i], w.qkv, C_PLANAR, w.ps_qkv, Me, 3 * inner, d, GRAM_EPI_BF16, nullptr,
                  i == 0 && !pre_rs ? &consume_embed : &consume, st));
-      TRY(cap_pieces(w, w.qkv, w.ps_qkv, GRAM_STAGE_ENC_ATTN, st));
-      TRY(gram_enc_self_attn_split(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, w.pieces, w.ps_qkv, w.ps_attn, st));
-      TRY(cap_pieces(w, w.attn, w.ps_attn, GRAM_STAGE_ENC_ATTN, st));
-      TRY(linear(w, w.attn, w.ps_attn, m->enc_wo[i], w.x, w.ps_h, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(cap_planar(w, w.qkv, w.ps_qkv, GRAM_STAGE_ENC_ATTN, st));
+      TRY(gram_enc_self_attn_split(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, w.pieces, w.ps_qkv, st));
+      TRY(cap_inter(w, w.attn, Me, inner, GRAM_STAGE_ENC_ATTN, st));
+      TRY(linear(w, w.attn, m->enc_wo[i], m->s_enc_wo[i], w.x, C_NONE, 0, Me, d, inner, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
-      TRY(cap_pieces(w, w.h, w.ps_h, GRAM_STAGE_ENC_FFN, st));
-      TRY(linear(w, w.h, w.ps_h, m->enc_wi[i], w.u, w.ps_u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
-      TRY(cap_pieces(w, w.u, w.ps_u, GRAM_STAGE_ENC_FFN, st));
-      TRY(linear(w, w.u, w.ps_u, m->enc_wo2[i], w.x, w.ps_h, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(cap_inter(w, w.h, Me, d, GRAM_STAGE_ENC_FFN, st));
+      TRY(linear(w, w.h, m->enc_wi[i], m->s_enc_wi[i], w.u, C_INTER, 0, Me, F, d, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
+      TRY(cap_inter(w, w.u, Me, F, GRAM_STAGE_ENC_FFN, st));
+      TRY(linear(w, w.u, m->enc_wo2[i], m->s_enc_wo2[i], w.x, C_NONE, 0, Me, d, F, GRAM_EPI_F32_ADD, nullptr, &produce, st));
     }
-  } else {
+  } else {  // (one piece only: gram_model_create insists on fold_norm in the two-piece mode)
     TRY(gram_embed_i64(c.embed_f32, ids, w.x, Me, d, st));
     for (int i = 0; i < c.n_enc_layers; ++i) {
-      TRY(gram_rmsnorm_bf16_split(w.x, m->enc_ln1[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, nullptr, w.pieces, w.ps_h, st));
-      TRY(linear(w, w.h, w.ps_h, m->enc_wqkv[i], w.qkv, w.ps_qkv, Me, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, nullptr, st));
-      TRY(gram_enc_self_attn_split(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, w.pieces, w.ps_qkv, w.ps_attn, st));
-      TRY(linear(w, w.attn, w.ps_attn, m->enc_wo[i], w.x, 0, Me, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
-      TRY(gram_rmsnorm_bf16_split(w.x, m->enc_ln2[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, nullptr, w.pieces, w.ps_h, st));
-      TRY(linear(w, w.h, w.ps_h, m->enc_wi[i], w.u, w.ps_u, Me, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, nullptr, st));
-      TRY(linear(w, w.u, w.ps_u, m->enc_wo2[i], w.x, 0, Me, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
+      TRY(gram_rmsnorm_bf16_split(w.x, m->enc_ln1[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, nullptr, 1, st));
+      TRY(linear(w, w.h, m->enc_wqkv[i], m->s_enc_wqkv[i], w.qkv, C_PLANAR, 0, Me, 3 * inner, d, GRAM_EPI_BF16, nullptr, nullptr, st));
+      TRY(gram_enc_self_attn_split(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, 1, 0, st));
+      TRY(linear(w, w.attn, m->enc_wo[i], m->s_enc_wo[i], w.x, C_NONE, 0, Me, d, inner, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
+      TRY(gram_rmsnorm_bf16_split(w.x, m->enc_ln2[i], w.h, Me, d, c.eps, 1.f, nullptr, 1, 1, nullptr, 1, st));
+      TRY(linear(w, w.h, m->enc_wi[i], m->s_enc_wi[i], w.u, C_PLANAR, 0, Me, F, d, GRAM_EPI_BF16_RELU, nullptr, nullptr, st));
+      TRY(linear(w, w.u, m->enc_wo2[i], m->s_enc_wo2[i], w.x, C_NONE, 0, Me, d, F, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
     }
   }
   return 0;
@@ -279,12 +293,12 @@ int encode(const gram_model* m, const Workspace& w, const int64_t* ids, const ui
   // final norm + per-passage position embedding = the late fusion (gram.py:238-255); the
   // (B*N, L, d) -> (B, N*L, d) view is free: rows are already user-major.
   TRY(gram_rmsnorm_bf16_split(w.x, c.enc_final_ln, w.h, Me, d, c.eps, 1.f, c.use_position_embedding ? c.pos_emb_f32 : nullptr, N, L,
-                              pmap, w.pieces, w.ps_h, st));
+                              pmap, w.pieces, st));
   // every decoder layer's cross K/V in ONE GEMM, scattered into the beam-shared bank
   gram_kv_bank_t bank{w.bank_k, w.bank_vt, c.n_dec_layers, B, H, N * L, pmap, N, L};
-  TRY(linear(w, w.h, w.ps_h, c.dec_wkv_x_all, nullptr, w.ps_bank, Me, c.n_dec_layers * 2 * inner, d, d, 0, GRAM_EPI_KV_BANK, &bank, nullptr, st));
-  TRY(cap_pieces(w, w.bank_k, w.ps_bank, GRAM_STAGE_BANK_K, st));
-  TRY(cap_pieces(w, w.bank_vt, w.ps_bank, GRAM_STAGE_BANK_V, st));
+  TRY(linear(w, w.h, c.dec_wkv_x_all, m->s_wkv, nullptr, C_NONE, 0, Me, c.n_dec_layers * 2 * inner, d, GRAM_EPI_KV_BANK, &bank, nullptr, st));
+  TRY(cap_planar(w, w.bank_k, w.ps_bank, GRAM_STAGE_BANK_K, st));
+  TRY(cap_planar(w, w.bank_vt, w.ps_bank, GRAM_STAGE_BANK_V, st));
   return 0;
 }
 
@@ -303,13 +317,12 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   const int R = live ? live->n_rows : B * K, S = N * L;
   auto self_attn = [&](int i, size_t cache_layer) {
     return gram_dec_self_attn_split(w.qkvd, w.kcache + i * cache_layer, w.vcache + i * cache_layer, anc, c.dec_bias_f32, w.attnd,
-                                    live ? R_cache : R, R, live ? live->rows : nullptr, H, t, Tmax, w.pieces, w.ps_qkvd, w.ps_cache,
-                                    w.ps_attnd, st);
+                                    live ? R_cache : R, R, live ? live->rows : nullptr, H, t, Tmax, w.pieces, w.ps_qkvd, w.ps_cache, st);
   };
   auto cross_attn = [&](int i, size_t bank_layer) {
     return gram_cross_attn_decode_split(w.qx, w.bank_k + i * bank_layer, w.bank_vt + i * bank_layer, mask, w.attnd,
                                         live ? live->n_users : B, K, H, S, live ? live->users : nullptr, live ? live->rowpos : nullptr,
-                                        w.pieces, w.ps_qx, w.ps_bank, w.ps_attnd, w.key_bits, st);
+                                        w.pieces, w.ps_qx, w.ps_bank, w.key_bits, st);
   };
   const size_t bank_layer = (size_t)B * H * S * 64;
   const size_t cache_layer = (size_t)Tmax * R_cache * inner;
@@ -321,53 +334,53 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
     const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rsd, 0, d, c.eps, 0}
                                               : gram_norm_fusion_t{nullptr, nullptr, w.ssd, d / 64, d, c.eps, quarter};
     const gram_norm_fusion_t consume_embed{nullptr, nullptr, w.ssd, d / 64, d, c.eps, 0};
-    TRY(gram_embed_ex_split(c.embed_f32, tokens, 0, w.xd, w.hd, w.ssd, d / 64, R, d, w.pieces, w.ps_hd, st));
+    TRY(gram_embed_ex_split(c.embed_f32, tokens, 0, w.xd, w.hd, w.ssd, d / 64, R, d, w.pieces, st));
     for (int i = 0; i < c.n_dec_layers; ++i) {
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
-      TRY(cap_pieces(w, w.hd, w.ps_hd, GRAM_STAGE_DEC_SELF, st));
-      TRY(linear(w, w.hd, w.ps_hd, m->dec_wqkv[i], w.qkvd, w.ps_qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr,
+      TRY(cap_inter(w, w.hd, R, d, GRAM_STAGE_DEC_SELF, st));
+      TRY(linear(w, w.hd, m->dec_wqkv[i], m->s_dec_wqkv[i], w.qkvd, C_PLANAR, w.ps_qkvd, R, 3 * inner, d, GRAM_EPI_BF16, nullptr,
                  i == 0 && !pre_rs ? &consume_embed : &consume, st));
-      TRY(cap_pieces(w, w.qkvd, w.ps_qkvd, GRAM_STAGE_DEC_SELF, st));
+      TRY(cap_planar(w, w.qkvd, w.ps_qkvd, GRAM_STAGE_DEC_SELF, st));
       TRY(self_attn(i, cache_layer));
-      TRY(cap_pieces(w, w.attnd, w.ps_attnd, GRAM_STAGE_DEC_SELF, st));
-      TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo[i], w.xd, w.ps_hd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(cap_inter(w, w.attnd, R, inner, GRAM_STAGE_DEC_SELF, st));
+      TRY(linear(w, w.attnd, m->dec_wo[i], m->s_dec_wo[i], w.xd, C_NONE, 0, R, d, inner, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
-      TRY(cap_pieces(w, w.hd, w.ps_hd, GRAM_STAGE_DEC_CROSS, st));
-      TRY(linear(w, w.hd, w.ps_hd, m->dec_wq_x[i], w.qx, w.ps_qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, &consume, st));
-      TRY(cap_pieces(w, w.qx, w.ps_qx, GRAM_STAGE_DEC_CROSS, st));
+      TRY(cap_inter(w, w.hd, R, d, GRAM_STAGE_DEC_CROSS, st));
+      TRY(linear(w, w.hd, m->dec_wq_x[i], m->s_dec_wq_x[i], w.qx, C_PLANAR, w.ps_qx, R, inner, d, GRAM_EPI_BF16, nullptr, &consume, st));
+      TRY(cap_planar(w, w.qx, w.ps_qx, GRAM_STAGE_DEC_CROSS, st));
       TRY(cross_attn(i, bank_layer));
-      TRY(cap_pieces(w, w.attnd, w.ps_attnd, GRAM_STAGE_DEC_CROSS, st));
-      TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo_x[i], w.xd, w.ps_hd, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(cap_inter(w, w.attnd, R, inner, GRAM_STAGE_DEC_CROSS, st));
+      TRY(linear(w, w.attnd, m->dec_wo_x[i], m->s_dec_wo_x[i], w.xd, C_NONE, 0, R, d, inner, GRAM_EPI_F32_ADD, nullptr, &produce, st));
       if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
-      TRY(cap_pieces(w, w.hd, w.ps_hd, GRAM_STAGE_DEC_FFN, st));
-      TRY(linear(w, w.hd, w.ps_hd, m->dec_wi[i], w.ud, w.ps_ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
-      TRY(cap_pieces(w, w.ud, w.ps_ud, GRAM_STAGE_DEC_FFN, st));
-      TRY(linear(w, w.ud, w.ps_ud, m->dec_wo2[i], w.xd, w.ps_hd, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      TRY(cap_inter(w, w.hd, R, d, GRAM_STAGE_DEC_FFN, st));
+      TRY(linear(w, w.hd, m->dec_wi[i], m->s_dec_wi[i], w.ud, C_INTER, 0, R, F, d, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
+      TRY(cap_inter(w, w.ud, R, F, GRAM_STAGE_DEC_FFN, st));
+      TRY(linear(w, w.ud, m->dec_wo2[i], m->s_dec_wo2[i], w.xd, C_NONE, 0, R, d, F, GRAM_EPI_F32_ADD, nullptr, &produce, st));
     }
-  } else {
+  } else {  // (one piece only)
     TRY(gram_embed_i32(c.embed_f32, tokens, w.xd, R, d, st));
     for (int i = 0; i < c.n_dec_layers; ++i) {
-      TRY(gram_rmsnorm_bf16_split(w.xd, m->dec_ln1[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, nullptr, w.pieces, w.ps_hd, st));
-      TRY(linear(w, w.hd, w.ps_hd, m->dec_wqkv[i], w.qkvd, w.ps_qkvd, R, 3 * inner, d, d, 3 * inner, GRAM_EPI_BF16, nullptr, nullptr, st));
+      TRY(gram_rmsnorm_bf16_split(w.xd, m->dec_ln1[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, nullptr, 1, st));
+      TRY(linear(w, w.hd, m->dec_wqkv[i], m->s_dec_wqkv[i], w.qkvd, C_PLANAR, 0, R, 3 * inner, d, GRAM_EPI_BF16, nullptr, nullptr, st));
       TRY(self_attn(i, cache_layer));
-      TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo[i], w.xd, 0, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
-      TRY(gram_rmsnorm_bf16_split(w.xd, m->dec_ln2[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, nullptr, w.pieces, w.ps_hd, st));
-      TRY(linear(w, w.hd, w.ps_hd, m->dec_wq_x[i], w.qx, w.ps_qx, R, inner, d, d, inner, GRAM_EPI_BF16, nullptr, nullptr, st));
+      TRY(linear(w, w.attnd, m->dec_wo[i], m->s_dec_wo[i], w.xd, C_NONE, 0, R, d, inner, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
+      TRY(gram_rmsnorm_bf16_split(w.xd, m->dec_ln2[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, nullptr, 1, st));
+      TRY(linear(w, w.hd, m->dec_wq_x[i], m->s_dec_wq_x[i], w.qx, C_PLANAR, 0, R, inner, d, GRAM_EPI_BF16, nullptr, nullptr, st));
       TRY(cross_attn(i, bank_layer));
-      TRY(linear(w, w.attnd, w.ps_attnd, m->dec_wo_x[i], w.xd, 0, R, d, inner, inner, d, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
-      TRY(gram_rmsnorm_bf16_split(w.xd, m->dec_ln3[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, nullptr, w.pieces, w.ps_hd, st));
-      TRY(linear(w, w.hd, w.ps_hd, m->dec_wi[i], w.ud, w.ps_ud, R, F, d, d, F, GRAM_EPI_BF16_RELU, nullptr, nullptr, st));
-      TRY(linear(w, w.ud, w.ps_ud, m->dec_wo2[i], w.xd, 0, R, d, F, F, d, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
+      TRY(linear(w, w.attnd, m->dec_wo_x[i], m->s_dec_wo_x[i], w.xd, C_NONE, 0, R, d, inner, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
+      TRY(gram_rmsnorm_bf16_split(w.xd, m->dec_ln3[i], w.hd, R, d, c.eps, 1.f, nullptr, 1, 1, nullptr, 1, st));
+      TRY(linear(w, w.hd, m->dec_wi[i], m->s_dec_wi[i], w.ud, C_PLANAR, 0, R, F, d, GRAM_EPI_BF16_RELU, nullptr, nullptr, st));
+      TRY(linear(w, w.ud, m->dec_wo2[i], m->s_dec_wo2[i], w.xd, C_NONE, 0, R, d, F, GRAM_EPI_F32_ADD, nullptr, nullptr, st));
     }
   }
   const float scale = c.tie_word_embeddings ? 1.0f / sqrtf((float)d) : 1.f;  // gram_t5.py:249-252
-  TRY(gram_rmsnorm_bf16_split(w.xd, c.dec_final_ln, w.hd, R, d, c.eps, scale, nullptr, 1, 1, nullptr, w.pieces, w.ps_hd, st));
-  TRY(cap_pieces(w, w.hd, w.ps_hd, GRAM_STAGE_LM_HEAD, st));
-  const gram_split_t sp{w.pieces, w.ps_hd, 0, 0, 0};
+  TRY(gram_rmsnorm_bf16_split(w.xd, c.dec_final_ln, w.hd, R, d, c.eps, scale, nullptr, 1, 1, nullptr, w.pieces, st));
+  TRY(cap_inter(w, w.hd, R, d, GRAM_STAGE_LM_HEAD, st));
+  const gram_split_t sp{w.pieces, 0, 0, 0, m->s_lm};
   if (lse_part)  // log-softmax normaliser partials straight from the accumulators; logits may be NULL (not stored)
-    TRY(gram_gemm_bf16_lse_split(w.hd, c.lm_head_bf16, logits, lse_part, R, V, d, d, V, &sp, st));
+    TRY(gram_gemm_bf16_lse_split(w.hd, c.lm_head_bf16, logits, lse_part, R, V, d, w.pieces * d, V, &sp, st));
   else
-    TRY(gram_gemm_bf16_split(w.hd, c.lm_head_bf16, logits, R, V, d, d, V, GRAM_EPI_F32, nullptr, nullptr, &sp, st));
+    TRY(gram_gemm_bf16_split(w.hd, c.lm_head_bf16, logits, R, V, d, w.pieces * d, V, GRAM_EPI_F32, nullptr, nullptr, &sp, st));
   return 0;
 }
 
@@ -377,7 +390,7 @@ int search_step(const gram_model* m, const Workspace& w, const gram_trie_t* trie
   const gram_model_desc_t& c = m->d;
   if (w.pieces > 1)
     return gram_beam_step_sparse_split(&w.beam, trie, w.hd, c.lm_head_f32, c.d_model, w.lse, c.vocab, cur_len, rows_per_user, rowpos,
-                                       w.pieces, w.ps_hd, st);
+                                       w.pieces, st);
   if (rowpos) return gram_beam_step_sparse_live(&w.beam, trie, w.hd, c.lm_head_bf16, c.d_model, w.lse, c.vocab, cur_len, rowpos, st);
   return gram_beam_step_sparse(&w.beam, trie, w.hd, c.lm_head_bf16, c.d_model, w.lse, c.vocab, cur_len, rows_per_user, st);
 }
@@ -385,6 +398,7 @@ int search_step(const gram_model* m, const Workspace& w, const gram_trie_t* trie
 }  // namespace
 
 extern "C" int gram_abi_version(void) { return GRAM_ABI_VERSION; }
+extern "C" int gram_piece_format(void) { return GRAM_PIECE_FORMAT; }
 
 extern "C" int gram_debug_set_stage_pieces(const int32_t* caps, int n) {
   if (caps && n != GRAM_STAGE_COUNT) return GRAM_E_ARG;
@@ -407,7 +421,7 @@ extern "C" gram_model_t* gram_model_create(const gram_model_desc_t* d) {
   if (!d || d->vocab % 128 || d->d_model % 128 || d->d_ff % 128 || d->n_heads < 1 || d->n_heads > 16 ||
       (d->n_heads * 64) % 128 || d->d_model > 1024 || d->n_enc_layers < 1 || d->n_dec_layers < 1)
     return nullptr;
-  if (d->pieces < 0 || d->pieces > GRAM_MAX_PIECES || (d->pieces > 1 && !d->lm_head_f32)) return nullptr;
+  if (d->pieces < 0 || d->pieces > GRAM_MAX_PIECES || (d->pieces > 1 && (!d->lm_head_f32 || !d->fold_norm))) return nullptr;
   gram_model* m = new gram_model();
   m->d = *d;
   auto cpf = [](std::vector<const float*>& v, const float* const* src, int n) { v.assign(src, src + n); };
@@ -427,6 +441,31 @@ extern "C" gram_model_t* gram_model_create(const gram_model_desc_t* d) {
   cpv(m->dec_wo_x, d->dec_wo_x, d->n_dec_layers);
   cpv(m->dec_wi, d->dec_wi, d->n_dec_layers);
   cpv(m->dec_wo2, d->dec_wo2, d->n_dec_layers);
+  {
+    const float* ws = d->w_scales;
+    auto take = [&](std::vector<float>& v, int n) {
+      v.assign(n, 1.f);
+      if (ws) {
+        for (int i = 0; i < n; ++i) v[i] = 1.f / ws[i];
+        ws += n;
+      }
+    };
+    take(m->s_enc_wqkv, d->n_enc_layers);
+    take(m->s_enc_wo, d->n_enc_layers);
+    take(m->s_enc_wi, d->n_enc_layers);
+    take(m->s_enc_wo2, d->n_enc_layers);
+    take(m->s_dec_wqkv, d->n_dec_layers);
+    take(m->s_dec_wo, d->n_dec_layers);
+    take(m->s_dec_wq_x, d->n_dec_layers);
+    take(m->s_dec_wo_x, d->n_dec_layers);
+    take(m->s_dec_wi, d->n_dec_layers);
+    take(m->s_dec_wo2, d->n_dec_layers);
+    if (ws) {
+      m->s_wkv = 1.f / ws[0];
+      m->s_lm = 1.f / ws[1];
+    }
+    m->d.w_scales = nullptr;  // (consumed)
+  }
   // the descriptor's per-layer arrays now point at storage the handle owns
   m->d.enc_ln1 = m->enc_ln1.data();
   m->d.enc_ln2 = m->enc_ln2.data();
@@ -467,7 +506,7 @@ extern "C" int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
   TRY(encode(m, w, input_ids, mask, mask, B, N, L, B * N, nullptr, CachedPassages{0, 0, nullptr, nullptr}, stream));
   if (enc_out_bf16) {  // (split modes: all the pieces, [pieces][B*N*L][d])
-    hipError_t e = hipMemcpyAsync(enc_out_bf16, w.h, (size_t)w.pieces * B * N * L * m->d.d_model * sizeof(bf16), hipMemcpyDeviceToDevice,
+    hipError_t e = hipMemcpyAsync(enc_out_bf16, w.h, (size_t)w.pieces * B * N * L * m->d.d_model * sizeof(bf16), hipMemcpyDeviceToDevice,  // (interleaved rows)
                                   (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
@@ -604,7 +643,7 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
   } else {
     gram_model* mm = const_cast<gram_model*>(m);
     GraphEntry key{B, N, L, K, nret, max_length, length_penalty, workspace, trie->child_off, trie->child_tok, trie->child_node,
-                   trie->n_nodes, trie->n_edges, trie->max_fanout, trie->min_seq_len, nullptr};
+                   trie->n_nodes, trie->n_edges, trie->max_fanout, trie->min_seq_len, nullptr, false};
     GraphEntry* hit = nullptr;
     for (auto& g : mm->graphs)
       if (g.B == B && g.N == N && g.L == L && g.K == K && g.nret == nret && g.Tmax == max_length && g.lp == length_penalty &&
@@ -622,6 +661,10 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
         mm->graphs.clear();
       }
       mm->graphs.push_back(key);
+      // (capturing = true: no live-row compaction, i.e. exactly the kernels and instantiations the capture will launch)
+      TRY(generate_body(m, w, w.ids_stage, w.mask_stage, B, N, L, K, nret, max_length, trie, nullptr, w.seq_stage, w.score_stage, true,
+                        stream));
+    } else if (hit->failed) {
       TRY(generate_body(m, w, w.ids_stage, w.mask_stage, B, N, L, K, nret, max_length, trie, nullptr, w.seq_stage, w.score_stage, false,
                         stream));
     } else {
@@ -638,12 +681,14 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
         e = hipStreamEndCapture(mm->cap_stream, &graph);
         if (rc != 0 || e != hipSuccess || !graph) {
           if (graph) (void)hipGraphDestroy(graph);
+          hit->failed = true;  // later calls of this shape launch eagerly instead of re-capturing every time
           return rc != 0 ? rc : (int)e;
         }
         e = hipGraphInstantiate(&hit->exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) {
           hit->exec = nullptr;
+          hit->failed = true;
           return (int)e;
         }
       }

@@ -5,8 +5,9 @@
 
 namespace {
 
-// bf16 pieces of 4 values (gram_split_t): piece p = bf16(v - p0 - .. - p_{p-1}), stored pstride elements apart
-__device__ __forceinline__ void store_pieces4(bf16* dst, f32x4 v, int pieces, long pstride) {
+// 16-bit pieces of the 4 values at columns n .. n+3 of a row (gram_split_t): piece p = r16(v - p0 - .. - p_{p-1}); one piece: the
+// plain row [d]; two pieces: the interleaved row [d / 32][2][32] (the layout a GEMM reads its A operand in)
+__device__ __forceinline__ void store_pieces4(bf16* row, int n, f32x4 v, int pieces) {
   for (int pc = 0; pc < pieces; ++pc) {
     bf16x4 o;
 #pragma unroll
@@ -14,7 +15,7 @@ __device__ __forceinline__ void store_pieces4(bf16* dst, f32x4 v, int pieces, lo
       o[e] = (bf16)v[e];
       v[e] -= (float)o[e];
     }
-    *reinterpret_cast<bf16x4*>(dst + pc * pstride) = o;
+    *reinterpret_cast<bf16x4*>(row + (pieces == 2 ? inter_off(n, pc) : n)) = o;
   }
 }
 
@@ -33,18 +34,18 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ ta
 template <typename IdT>
 __global__ __launch_bounds__(256) void embed_ex_kernel(const float* __restrict__ table, const IdT* __restrict__ ids,
                                                        float* __restrict__ x, bf16* __restrict__ xb, float* __restrict__ ss,
-                                                       int nblk, int rows, int d, int pieces, long pstride) {
+                                                       int nblk, int rows, int d, int pieces) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const f32x4* src = reinterpret_cast<const f32x4*>(table + (size_t)ids[row] * d);
   f32x4* dst = reinterpret_cast<f32x4*>(x + (size_t)row * d);
-  bf16* dstb = xb + (size_t)row * d;
+  bf16* dstb = xb + (size_t)row * d * pieces;
   float s = 0.f;
   for (int i = lane; i < d / 4; i += 64) {
     const f32x4 v = src[i];
     dst[i] = v;
-    store_pieces4(dstb + 4 * i, v, pieces, pstride);
+    store_pieces4(dstb, 4 * i, v, pieces);
     s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
   }
   s = wave_sum(s);
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void embed_ex_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       bf16* __restrict__ out, int rows, int d, float eps, float scale,
                                                       const float* __restrict__ pos, int N, int L,
-                                                      const int32_t* __restrict__ pmap, int pieces, long pstride) {
+                                                      const int32_t* __restrict__ pmap, int pieces) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   // passage index of this row: row / L, or through the compaction map (flat index b*N + n)
   const int pn = pos ? ((pmap ? pmap[row / L] : row / L) % N) : 0;
   const f32x4* pr = pos ? reinterpret_cast<const f32x4*>(pos + (size_t)pn * d) : nullptr;
-  bf16* o = out + (size_t)row * d;
+  bf16* o = out + (size_t)row * d * pieces;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     int i = lane + it * 64;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
       f32x4 r;
 #pragma unroll
       for (int e = 0; e < 4; ++e) r[e] = g[e] * (v[it][e] * rs) * scale + p[e];
-      store_pieces4(o + 4 * i, r, pieces, pstride);
+      store_pieces4(o, 4 * i, r, pieces);
     }
   }
 }
@@ -311,21 +312,20 @@ extern "C" int gram_lse_combine(const float* lse_part, float* lse, int M, int nb
 
 extern "C" int gram_embed_ex(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk,
                              int rows, int d, void* stream) {
-  return gram_embed_ex_split(table, ids, ids_are_i64, x, xb, ss, nblk, rows, d, 1, 0, stream);
+  return gram_embed_ex_split(table, ids, ids_are_i64, x, xb, ss, nblk, rows, d, 1, stream);
 }
 
 extern "C" int gram_embed_ex_split(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk,
-                                   int rows, int d, int pieces, int64_t xb_pstride, void* stream) {
-  if (rows < 1 || (d & 3) || !xb || !ss || nblk < 1 || nblk > 64 || pieces < 1 || pieces > GRAM_MAX_PIECES ||
-      (pieces > 1 && xb_pstride < (int64_t)rows * d))
+                                   int rows, int d, int pieces, void* stream) {
+  if (rows < 1 || (d & 3) || !xb || !ss || nblk < 1 || nblk > 64 || pieces < 1 || pieces > GRAM_MAX_PIECES || (pieces > 1 && (d & 31)))
     return GRAM_E_ARG;
   gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, (8.0 + 2.0 * pieces) * rows * d);
   if (ids_are_i64)
     hipLaunchKernelGGL(embed_ex_kernel<int64_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, (const int64_t*)ids,
-                       x, (bf16*)xb, ss, nblk, rows, d, pieces, (long)xb_pstride);
+                       x, (bf16*)xb, ss, nblk, rows, d, pieces);
   else
     hipLaunchKernelGGL(embed_ex_kernel<int32_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, (const int32_t*)ids,
-                       x, (bf16*)xb, ss, nblk, rows, d, pieces, (long)xb_pstride);
+                       x, (bf16*)xb, ss, nblk, rows, d, pieces);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -351,14 +351,12 @@ extern "C" int gram_rmsnorm_bf16(const float* x, const float* w, void* out, int 
 
 extern "C" int gram_rmsnorm_bf16_map(const float* x, const float* w, void* out, int rows, int d, float eps, float scale,
                                      const float* pos, int N, int L, const int32_t* passage_map, void* stream) {
-  return gram_rmsnorm_bf16_split(x, w, out, rows, d, eps, scale, pos, N, L, passage_map, 1, 0, stream);
+  return gram_rmsnorm_bf16_split(x, w, out, rows, d, eps, scale, pos, N, L, passage_map, 1, stream);
 }
 
 extern "C" int gram_rmsnorm_bf16_split(const float* x, const float* w, void* out, int rows, int d, float eps, float scale,
-                                       const float* pos, int N, int L, const int32_t* passage_map, int pieces, int64_t out_pstride,
-                                       void* stream) {
-  if (rows < 1 || (d & 3) || d > 1024 || (pos && (N < 1 || L < 1)) || pieces < 1 || pieces > GRAM_MAX_PIECES ||
-      (pieces > 1 && out_pstride < (int64_t)rows * d))
+                                       const float* pos, int N, int L, const int32_t* passage_map, int pieces, void* stream) {
+  if (rows < 1 || (d & 3) || d > 1024 || (pos && (N < 1 || L < 1)) || pieces < 1 || pieces > GRAM_MAX_PIECES || (pieces > 1 && (d & 31)))
     return GRAM_E_ARG;
   if (!pos) {
     N = 1;
@@ -366,7 +364,7 @@ extern "C" int gram_rmsnorm_bf16_split(const float* x, const float* w, void* out
   }
   gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, (4.0 + 2.0 * pieces) * rows * d);
   hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)out, rows, d, eps,
-                     scale, pos, N, L, passage_map, pieces, (long)out_pstride);
+                     scale, pos, N, L, passage_map, pieces);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

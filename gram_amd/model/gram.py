@@ -133,7 +133,7 @@ class GRAM(nn.Module):
         self._tries: Dict[int, tuple] = {}  # id(trie) -> (trie, FlatTrie)
         # The reference computes in fp32; "bf16x3" is the cheapest arithmetic that keeps Recall@5 / NDCG@5 within 1e-4 of it
         # (DESIGN.md §5), so it is what a drop-in model starts in.  GRAM_PRECISION / set_precision() choose another.
-        self._precision = os.environ.get("GRAM_PRECISION", "bf16x3")
+        self._precision = os.environ.get("GRAM_PRECISION", self.default_precision())
         if self._precision not in self.PRECISIONS:
             raise ValueError(f"GRAM_PRECISION={self._precision!r}: choose from {self.PRECISIONS}")
         self._pcache = None  # passage cache: dict(x, canon, keys, perm) on the device
@@ -181,8 +181,14 @@ class GRAM(nn.Module):
 
     # "bf16": bf16 operands (8 significant bits).  "bf16x3" / "bf16x6": every value travels as 2 / 3 bf16 pieces and every
     # product is 3 / 6 bf16 MFMA products (gram_hip.h, gram_split_t): ~2^-18 / fp32-class relative error at 3x / 6x the MFMA work.
-    PRECISIONS = ("bf16", "bf16x3", "bf16x6")
-    _PIECES = {"bf16": 1, "bf16x3": 2, "bf16x6": 3}
+    # The 16-bit type is a property of the library build (gram_piece_format(): libgram_hip.so on bfloat16, PIECE=f16 builds on IEEE
+    # half -- 11 significant bits per piece, ~2^-22 for two pieces); the mode's prefix must name the loaded library's type.
+    PRECISIONS = ("bf16", "bf16x3", "f16", "f16x3")
+    _PIECES = {"bf16": 1, "bf16x3": 2, "f16": 1, "f16x3": 2}
+
+    @staticmethod
+    def default_precision() -> str:
+        return "f16x3" if _lib.load().gram_piece_format() == 1 else "bf16x3"
 
     def set_precision(self, mode: str) -> None:
         """Arithmetic of the GEMM / attention operands (accumulation, residual stream, softmax and scores are fp32 in
@@ -265,20 +271,36 @@ class GRAM(nn.Module):
             return t.data_ptr()
 
         pieces = self._PIECES[self._precision]
+        f16 = lib.gram_piece_format() == 1
+        if self._precision.startswith("f16") != f16:
+            raise _lib.GramHipError(f"precision {self._precision!r} needs the {'f16' if not f16 else 'bf16'} build of libgram_hip "
+                                    f"(loaded: {_lib.LIB_PATH}; GRAM_LIB selects another build)")
+        tdt = torch.float16 if f16 else torch.bfloat16
+        w_scales = []
 
         caps = self._stage_caps
 
-        def b16(t, stage=None, row_caps=None):
-            """[out][in] fp32 -> the MFMA weight operand: bf16, or (split modes) the product-expanded [out][nprod*in] matrix
-            whose chunk c holds piece SPLIT_W_PIECE[c] of W = p0 + p1 (+ p2), p_i = bf16(W - p0 - .. - p_{i-1}).
-            stage / row_caps: sensitivity sweeps (set_stage_pieces) -- pieces >= the stage's cap are zeroed (per row: row_caps)."""
+        def b16(t, stage=None, row_caps=None, no_scale=False):
+            """[out][in] fp32 -> the MFMA weight operand: one 16-bit matrix, or (two-piece mode) the INTERLEAVED [out][in/32][2][32]
+            matrix of W = p0 + p1, p0 = r16(W), p1 = r16(W - p0): a 64-column k-tile holds both pieces of a 32-column block.
+            stage / row_caps: sensitivity sweeps (set_stage_pieces) -- the upper piece is zeroed (per row: row_caps)."""
             t = t.to(dev, torch.float32)
+            # f16 build: the matrix is scaled by a power of two so that its largest entry sits in [2^13, 2^14) -- the low pieces of
+            # small weights then stay normal numbers (an f16 subnormal keeps fewer bits); the GEMM multiplies its result by the
+            # inverse (gram_model_desc_t.w_scales).  The 16-bit lm_head of the one-piece mode is read unscaled by the beam kernel.
+            scale = 1.0
+            if f16 and not (no_scale and pieces == 1):
+                amax = float(t.abs().max())
+                if amax > 0.0 and math.isfinite(amax):
+                    scale = 2.0 ** (13 - math.floor(math.log2(amax)))
+                t = t * scale
+            w_scales.append(scale)
             if pieces == 1:
-                t = t.to(torch.bfloat16).contiguous()
+                t = t.to(tdt).contiguous()
             else:
                 ps, r = [], t.clone()
                 for _ in range(pieces):
-                    ps.append(r.to(torch.bfloat16))
+                    ps.append(r.to(tdt))
                     r -= ps[-1].float()
                 cap = caps.get(stage, 99) if stage else 99
                 for j in range(pieces):
@@ -286,7 +308,7 @@ class GRAM(nn.Module):
                         ps[j].zero_()
                     elif row_caps is not None:
                         ps[j][row_caps.to(dev) <= j] = 0
-                t = torch.cat([ps[j] for j in _lib.SPLIT_W_PIECE[pieces]], dim=1).contiguous()
+                t = _lib.interleave(torch.stack(ps))
             keep.append(t)
             return t.data_ptr()
 
@@ -331,7 +353,7 @@ class GRAM(nn.Module):
             vocab=c.vocab_size, d_model=c.d_model, d_ff=c.d_ff, n_heads=H, n_enc_layers=ne, n_dec_layers=nd,
             max_passages=self.max_item_num + 1, tie_word_embeddings=int(bool(getattr(c, "tie_word_embeddings", True))),
             use_position_embedding=int(self.use_position_embedding), fold_norm=int(fold), eps=float(c.layer_norm_epsilon),
-            embed_f32=f32(sd["shared.weight"]), lm_head_bf16=b16(sd["lm_head.weight"], "lm_head"),
+            embed_f32=f32(sd["shared.weight"]), lm_head_bf16=b16(sd["lm_head.weight"], "lm_head", no_scale=True),
             pos_emb_f32=f32(sd["position_embedding.weight"]) if self.use_position_embedding else None,
             enc_bias_f32=f32(enc_bias), dec_bias_f32=f32(dec_bias),
             enc_final_ln=f32(sd["encoder.encoder.final_layer_norm.weight"]),
@@ -354,6 +376,13 @@ class GRAM(nn.Module):
             dec_wkv_x_all=b16(wkv_all, None, kv_row_caps),
             pieces=pieces, lm_head_f32=f32(sd["lm_head.weight"]) if pieces > 1 else None,
         )
+        # b16() ran in the field order of the constructor call above: lm_head first, then the per-layer families, then wkv_all.
+        # gram_model_desc_t.w_scales wants [enc_wqkv][enc_wo][enc_wi][enc_wo2][dec_wqkv][dec_wo][dec_wq_x][dec_wo_x][dec_wi][dec_wo2][wkv][lm_head]
+        assert len(w_scales) == 4 * ne + 6 * nd + 2
+        order = w_scales[1:] + w_scales[:1]
+        arr = (C.c_float * len(order))(*order)
+        keep.append(arr)
+        desc.w_scales = C.cast(arr, C.POINTER(C.c_float))
         handle = lib.gram_model_create(C.byref(desc))
         if not handle:
             raise _lib.GramHipError("gram_model_create rejected the configuration (dims must be multiples of 128, heads <= 16)")

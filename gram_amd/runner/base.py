@@ -155,14 +155,14 @@ class BaseRunner:
         encoded = self.encode_candidates(candidates)
         trie = gt.Trie(encoded)
         fn = gt.prefix_allowed_tokens_fn(trie)
-        # single_runner_gram.py:633-641, hoisted out of the loop: the longest candidate for the "t5_token" / "split" id types,
-        # 50 for the others.  Every candidate of those other types ends with the tokenizer's EOS, so all beams are finished
-        # by the Trie's depth and HF leaves the loop there: clamping 50 to that depth returns the same sequences and scores.
+        # single_runner_gram.py:633-641, hoisted out of the loop: the longest candidate for the "t5_token" / "split" id types.  The
+        # reference passes max_length = 50 for every other id type; the kernels stop at GRAM_MAX_DEC_LEN = 32 and a clamp to the Trie's
+        # depth equals HF's result only when every user has K finished hypotheses by then (otherwise HF keeps decoding -inf beams to
+        # 50 and finalizes differently) -- not implemented rather than approximately right.  The reference's datasets use "split".
         max_length = max(len(c) for c in encoded)
         if isinstance(candidates[0], str) and _arg(self.args, "item_id_type", "split") not in ("t5_token", "split"):
-            if max_length > 50 or not all(c[-1] == 1 for c in encoded):
-                raise ValueError("item_id_type %r: candidates must end with EOS and fit in max_length=50 (single_runner_gram.py:641)"
-                                 % _arg(self.args, "item_id_type", None))
+            raise NotImplementedError("item_id_type %r decodes with max_length=50 in the reference (single_runner_gram.py:633-641); this "
+                                      "build implements the 't5_token' and 'split' id types" % _arg(self.args, "item_id_type", None))
         K = self.generate_num
         model = self._generate_model()
         ranks, user_ids, examples, total_time = [], [], [], 0.0
@@ -177,8 +177,8 @@ class BaseRunner:
                     prefix_allowed_tokens_fn=fn, num_beams=K, num_return_sequences=K, output_scores=True,
                     return_dict_in_generate=True, length_penalty=self.length_penalty,
                 )
+                total_time += time() - start  # generate() alone, as single_runner_gram.py:640-652 times it (it returns synchronised)
                 scores = pred["sequences_scores"].detach().cpu().numpy()
-                total_time += time() - start
                 gold = self._decode(batch["target_ids"])
                 gen = self._decode(pred["sequences"])
                 rel = evaluate.rel_results(gen, gold, scores, K)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GRAM_ABI_VERSION 4
+#define GRAM_ABI_VERSION 5
 
 #define GRAM_E_ARG (-1)       /* bad shape / unsupported size                           */
 #define GRAM_E_WORKSPACE (-2) /* workspace too small (see gram_workspace_bytes)          */
@@ -96,59 +96,59 @@ int gram_row_rscale(const float* ss, float* rs, int M, int nblk, int d, float ep
 int gram_embed_ex(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk, int rows,
                   int d, void* stream);
 
-/* ---- split-bf16 operands: fp32-class arithmetic on the bf16 MFMA ("bf16x3", "bf16x6") --------------------
+/* ---- two-piece operands: fp32-class arithmetic on the 16-bit MFMA ("f16x3" / "bf16x3") --------------------------------
  * The reference computes in fp32 end to end (no autocast / half anywhere in src/; fp32 softmax gram_t5_modeling.py:608).
- * Plain bf16 operands carry 8 significant bits, which moves Recall@5/NDCG@5 by ~5e-3 on a 2 048-user population
- * (profiles/r02_precision_*.json) -- 50x the 1e-4 bound.  In the split modes a value v travels as `pieces` bf16 numbers
- *     p0 = bf16(v),  p1 = bf16(v - p0),  p2 = bf16(v - p0 - p1)
- * and a product a*w is evaluated on the bf16 MFMA as the sum of piece products, accumulated in fp32 smallest first:
- *     pieces = 2:  a0*w1 + a1*w0 + a0*w0                              3 MFMAs, relative error ~2^-18
- *     pieces = 3:  a0*w2 + a2*w0 + a1*w1 + a1*w0 + a0*w1 + a0*w0      6 MFMAs, ~2^-26 (below fp32's own rounding)
- * Layouts: every bf16 buffer (activations, Q/K/V, the KV bank, the self-attention cache) becomes `pieces` copies of its
- * plain layout, piece p starting `pstride` elements after piece p - 1.  A weight matrix [N][kc] is expanded on the host to
- * [N][nprod * kc]: chunk c (columns [c*kc, (c+1)*kc)) holds W piece GRAM_SPLIT_W_PIECE[pieces][c] and meets A piece
- * GRAM_SPLIT_A_PIECE[pieces][c].  pieces = 1 is the plain bf16 path (all *_split entry points accept split = NULL). */
-#define GRAM_MAX_PIECES 3
-static const int GRAM_SPLIT_NPROD[GRAM_MAX_PIECES + 1] = {0, 1, 3, 6};
-static const int GRAM_SPLIT_A_PIECE[GRAM_MAX_PIECES + 1][6] = {{0}, {0}, {0, 1, 0}, {0, 2, 1, 1, 0, 0}};
-static const int GRAM_SPLIT_W_PIECE[GRAM_MAX_PIECES + 1][6] = {{0}, {0}, {1, 0, 0}, {2, 0, 1, 0, 1, 0}};
+ * One 16-bit piece per value moves Recall@5/NDCG@5 by ~5e-3 (bf16) on a 2 048-user population -- 50x the 1e-4 bound.  With
+ * gram_split_t.pieces = 2 a value v travels as TWO 16-bit numbers
+ *     p0 = r16(v),  p1 = r16(v - p0)              (r16 = round to the library's 16-bit type, gram_piece_format())
+ * and a product a*w is evaluated on the 16-bit MFMA as three piece products accumulated in fp32, smallest first:
+ *     a0*w1 + a1*w0 + a0*w0          relative error ~2^-22 with IEEE-half pieces (11 significant bits each), ~2^-18 with bf16
+ * Layouts.  GEMM operands are INTERLEAVED: a logical [rows][K] matrix is stored as [rows][K/32][2][32] -- the two pieces of a
+ * 32-column block side by side, 128 B -- so that one 64-column k-tile of the physical [rows][2K] matrix carries everything the
+ * three products of that block need and is fetched once (inter(n, p) = (n / 32) * 64 + p * 32 + n % 32).  This holds for every
+ * activation a GEMM reads (the normed / copied residual stream, attention outputs, the FFN intermediate) and for every weight
+ * matrix.  What only attention kernels read -- Q/K/V rows, the KV bank, the self-attention cache -- stays PLANAR: `pieces`
+ * copies of the plain layout, `*_pstride` elements apart.  pieces = 1 is the plain path (every *_split entry point accepts
+ * split = NULL). */
+#define GRAM_MAX_PIECES 2
 typedef struct {
-  int32_t pieces;       /* 1 .. GRAM_MAX_PIECES                                                     */
-  int64_t a_pstride;    /* elements between the pieces of A                                         */
-  int64_t c_pstride;    /* ... of a bf16 C (GRAM_EPI_BF16, GRAM_EPI_BF16_RELU)                      */
-  int64_t xb_pstride;   /* ... of gram_norm_fusion_t.xb_out                                         */
-  int64_t bank_pstride; /* ... of gram_kv_bank_t.k and .vt                                          */
+  int32_t pieces;         /* 1 or 2                                                                                   */
+  int32_t c_interleaved;  /* a 16-bit C (GRAM_EPI_BF16[_RELU]) is written interleaved ([M][ldc >= 2N]) instead of planar  */
+  int64_t c_pstride;      /* planar 16-bit C: elements between its pieces                                              */
+  int64_t bank_pstride;   /* elements between the pieces of gram_kv_bank_t.k and .vt                                   */
+  float out_scale;        /* every result is acc * out_scale; 0 = 1.  Must be a power of two (GRAM_E_ARG otherwise): the
+                             inverse of the factor the caller scaled W by (gram_model_desc_t.w_scales)                  */
 } gram_split_t;
-/* gram_gemm_bf16_ex on split operands: A is `pieces` copies of [M][lda], W the expanded [N][nprod*kc] matrix, kc the
- * LOGICAL reduction length; bf16 results are written as pieces, fp32 results (residual stream, logits, LSE) as fp32. */
+/* gram_gemm_bf16_ex on two-piece operands: A is the interleaved [M][lda >= 2 kc] matrix, W the interleaved [N][2 kc] one, kc the
+ * LOGICAL reduction length; 16-bit results are written as pieces (C planar or interleaved as split says; gram_norm_fusion_t.xb_out
+ * always interleaved, [M][2 ldc]; the bank planar), fp32 results (residual stream, logits, LSE) as fp32. */
 int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M, int N, int kc, int lda, int ldc, int epilogue,
                          const gram_kv_bank_t* bank_host, const gram_norm_fusion_t* nf_host, const gram_split_t* split_host,
                          void* stream);
 int gram_gemm_bf16_lse_split(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int kc, int lda,
                              int ldc, const gram_split_t* split_host, void* stream);
 
-/* The other kernels on split operands.  Every bf16 input/output is `pieces` copies of the plain layout, *_pstride
- * elements apart; masks, bias tables, fp32 tensors and integer state are as in the plain entry points. */
+/* The other kernels on two-piece operands.  Masks, bias tables, fp32 tensors and integer state are as in the plain entry points.
+ * Outputs that feed a GEMM (xb, the norm's out, the attention outputs) are interleaved ([rows][2 * cols]) when pieces = 2; Q/K/V
+ * inputs, the bank and the cache are planar, *_pstride elements apart. */
 int gram_embed_ex_split(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk, int rows,
-                        int d, int pieces, int64_t xb_pstride, void* stream);
+                        int d, int pieces, void* stream);
 int gram_rmsnorm_bf16_split(const float* x, const float* w, void* out_bf16, int rows, int d, float eps, float scale,
-                            const float* pos, int N, int L, const int32_t* passage_map, int pieces, int64_t out_pstride,
-                            void* stream);
+                            const float* pos, int N, int L, const int32_t* passage_map, int pieces, void* stream);
 int gram_enc_self_attn_split(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H,
-                             int pieces, int64_t qkv_pstride, int64_t out_pstride, void* stream);
+                             int pieces, int64_t qkv_pstride, void* stream);
 /* users/rowpos NULL: all B users, rows b*K + beam; else the live-row form (gram_cross_attn_decode_live, B = n_users).
  * key_bits: gram_mask_key_bits(mask) computed once per generate (the mask is the same for every head, layer and step), or
  * NULL: every workgroup packs its user's bits from the mask bytes itself. */
 int gram_cross_attn_decode_split(const void* q, const void* k_layer, const void* vt_layer, const uint8_t* mask, void* out, int B,
                                  int K, int H, int S, const int32_t* users, const int32_t* rowpos, int pieces,
-                                 int64_t q_pstride, int64_t bank_pstride, int64_t out_pstride, const uint32_t* key_bits,
-                                 void* stream);
+                                 int64_t q_pstride, int64_t bank_pstride, const uint32_t* key_bits, void* stream);
 /* key_bits u32 [B][128]: bit j of word st = mask[b][32*st + j] != 0 (st < S/32). */
 int gram_mask_key_bits(const uint8_t* mask, uint32_t* key_bits, int B, int S, void* stream);
 /* rows NULL: all R rows; else the live-row form (gram_dec_self_attn_live). */
 int gram_dec_self_attn_split(const void* qkv, void* kcache, void* vcache, const int32_t* anc, const float* bias, void* out,
                              int R, int n_rows, const int32_t* rows, int H, int t, int Tmax, int pieces, int64_t qkv_pstride,
-                             int64_t cache_pstride, int64_t out_pstride, void* stream);
+                             int64_t cache_pstride, void* stream);
 /* lm_head with the log-softmax normaliser fused: logits as GRAM_EPI_F32, plus for every row and every
  * 64-column block the pair (max, sum exp(x - max)) in lse_part f32 [M][N/64][2]; gram_lse_combine folds
  * them into lse[M] = log sum_v exp(logits[m][v]) without re-reading the logits (gram_row_lse does).
@@ -280,11 +280,12 @@ int gram_beam_step_sparse_live(const gram_beam_state_t* st_host, const gram_trie
                                const void* lm_head_bf16, int d, const float* lse, int V, int cur_len,
                                const int32_t* rowpos, void* stream);
 
-/* gram_beam_step_sparse[_live] with the hidden state as pieces: the allowed logits are h . E[tok] in fp32, h the fp32 sum
- * of the pieces and E the FP32 lm_head table [V][d] (rowpos NULL: rows b*K + beam, rows_per_user as in gram_beam_step). */
+/* gram_beam_step_sparse[_live] with the hidden state as pieces (interleaved [rows][2 d] when pieces = 2): the allowed logits are
+ * h . E[tok] in fp32, h the fp32 sum of the pieces and E the FP32 lm_head table [V][d] (rowpos NULL: rows b*K + beam,
+ * rows_per_user as in gram_beam_step). */
 int gram_beam_step_sparse_split(const gram_beam_state_t* st_host, const gram_trie_t* trie_host, const void* hidden_bf16,
                                 const float* lm_head_f32, int d, const float* lse, int V, int cur_len, int rows_per_user,
-                                const int32_t* rowpos, int pieces, int64_t hidden_pstride, void* stream);
+                                const int32_t* rowpos, int pieces, void* stream);
 
 /* HF 4.26 greedy_search (generate with num_beams == 1; BASELINE configs[0]) on the same state with K = 1:
  * argmax of the RAW logits over the Trie children (first maximum), finished users emit pad; finalize copies
@@ -329,11 +330,17 @@ typedef struct {
   const void* const* dec_wi;   /* [n_dec]  bf16 [d_ff][d]                                  */
   const void* const* dec_wo2;  /* [n_dec]  bf16 [d][d_ff]                                  */
   const void* dec_wkv_x_all;   /* bf16 [n_dec*2*inner][d]: per layer k rows then v rows     */
-  /* split-bf16 precision modes (gram_split_t): pieces = 2 ("bf16x3") or 3 ("bf16x6"); 0 / 1 = plain bf16.  Then EVERY bf16
-   * weight above is the product-expanded matrix [out][nprod * in] and lm_head_f32 [V][d] must be given too (the beam
-   * kernel's sparse logits).  fold_norm must be 1. */
+  /* two-piece mode (gram_split_t): pieces = 2 ("f16x3" / "bf16x3"); 0 / 1 = one piece.  Then EVERY 16-bit weight above is the
+   * interleaved two-piece matrix [out][in / 32][2][32] and lm_head_f32 [V][d] must be given too (the beam kernel's sparse
+   * logits).  fold_norm must be 1. */
   int32_t pieces;
   const float* lm_head_f32;
+  /* Power-of-two factors the 16-bit weight matrices above were multiplied by before they were rounded (HOST array, or NULL = all
+   * 1): [enc_wqkv x n_enc][enc_wo x n_enc][enc_wi x n_enc][enc_wo2 x n_enc][dec_wqkv x n_dec][dec_wo][dec_wq_x][dec_wo_x][dec_wi]
+   * [dec_wo2 x n_dec][dec_wkv_x_all][lm_head]  (4 n_enc + 6 n_dec + 2 floats).  Every GEMM multiplies its result by the inverse
+   * (gram_split_t.out_scale).  Used by the f16 build (gram_piece_format() == 1): an IEEE-half low piece of a small weight would
+   * otherwise be subnormal and lose bits; bf16 has fp32's exponent range and needs none. */
+  const float* w_scales;
 } gram_model_desc_t;
 
 typedef struct gram_model gram_model_t;
@@ -349,8 +356,8 @@ int64_t gram_workspace_bytes(const gram_model_t* m, int B, int N, int L, int K, 
 /* EncoderWrapper.forward + the fused-bank projection (gram.py:200-256; gram_t5_modeling.py
  * T5Stack encoder role; cross K/V projection :531-534 for every decoder layer at once).
  * input_ids i64 [B][N][L], mask u8 [B][N][L].  Writes the bank into the workspace; when
- * enc_out_bf16 != NULL also copies the fused encoder states there (tests): [B*N*L][d] bf16, or in the split modes
- * their pieces, [pieces][B*N*L][d]. */
+ * enc_out_bf16 != NULL also copies the fused encoder states there (tests): [B*N*L][d], or in the two-piece mode the
+ * interleaved [B*N*L][2 d]. */
 int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N,
                       int L, void* workspace, int64_t workspace_bytes, int K, int max_length,
                       void* enc_out_bf16, void* stream);
@@ -465,6 +472,9 @@ enum gram_stage {
 int gram_debug_set_stage_pieces(const int32_t* caps, int n);
 
 int gram_abi_version(void);
+/* 16-bit operand type this build of the library computes on: 0 = bfloat16, 1 = IEEE half ("f16": make PIECE=f16).  Every "bf16"
+ * pointer of this header is a pointer to that type. */
+int gram_piece_format(void);
 
 #ifdef __cplusplus
 }

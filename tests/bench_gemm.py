@@ -35,10 +35,10 @@ def main():
     for name, M, N, K, epi in shapes:
         if a.only and a.only != name:
             continue
-        A = (torch.randn(M, K, generator=g)).to(G.DEV).to(torch.bfloat16)
-        W = (torch.randn(N, K, generator=g) * K ** -0.5).to(G.DEV).to(torch.bfloat16)
+        A = (torch.randn(M, K, generator=g)).to(G.DEV).to(G.DT)
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).to(G.DEV).to(G.DT)
         f32 = epi in (_lib.EPI_F32_ADD, _lib.EPI_F32)
-        C = torch.zeros(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device=G.DEV)
+        C = torch.zeros(M, N, dtype=torch.float32 if f32 else G.DT, device=G.DEV)
         ref = (A[:256].float() @ W.float().T)
         if epi == _lib.EPI_BF16_RELU:
             ref = ref.clamp(min=0)
@@ -65,7 +65,7 @@ def main():
             if a.fuse and epi != _lib.EPI_F32:
                 import ctypes as ct
                 if epi == _lib.EPI_F32_ADD:
-                    xb = torch.empty(M, N, dtype=torch.bfloat16, device=G.DEV)
+                    xb = torch.empty(M, N, dtype=G.DT, device=G.DEV)
                     ss = torch.empty(M, N // 64, dtype=torch.float32, device=G.DEV)
                     nf = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
                 else:

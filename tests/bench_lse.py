@@ -11,8 +11,8 @@ from tests import gpu_util as G  # noqa: E402
 lib = _lib.load()
 M, N, K = int(sys.argv[1]) if len(sys.argv) > 1 else 81920, 32128, 768
 g = torch.Generator().manual_seed(0)
-A = torch.randn(M, K, generator=g).to(G.DEV).to(torch.bfloat16)
-W = (torch.randn(N, K, generator=g) * K ** -0.5).to(G.DEV).to(torch.bfloat16)
+A = torch.randn(M, K, generator=g).to(G.DEV).to(G.DT)
+W = (torch.randn(N, K, generator=g) * K ** -0.5).to(G.DEV).to(G.DT)
 part = torch.empty(M, N // 64, 2, dtype=torch.float32, device=G.DEV)
 for v in (3, 22, 3, 22):
     lib.gram_debug_set_gemm_variant(v)

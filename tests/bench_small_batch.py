@@ -1,6 +1,6 @@
 """Latency of one generate() call at small batch sizes (the reference evaluates one user per call: --eval_batch_size 1), configs[1]
 shapes (T5-base, 3 x 128 passages, Beauty Trie, beam 20).  Not collected by pytest.
-    python tests/bench_small_batch.py [--precision bf16x3] [--batches 1,2,4,8,16,32,64] [--iters 20]
+    python tests/bench_small_batch.py [--precision f16x3] [--batches 1,2,4,8,16,32,64] [--iters 20]
 A/B hooks are process-wide environment variables (GRAM_GEMM_STREAM_MAXM, ...): run it once per setting."""
 import argparse
 import json
@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--precision", default="f16x3")
     ap.add_argument("--batches", default="1,2,4,8,16,32,64")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--tag", default="")

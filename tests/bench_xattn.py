@@ -14,20 +14,21 @@ sys.path.insert(0, ROOT)
 def one(pieces, B=4096, H=12, S=384, K=20, reps=20, use_bits=True, layers=1):
     import torch
     from gram_amd import _lib
+    DT = _lib.piece_dtype()
     lib = _lib.load()
     dev = "cuda:0"
     inner = H * 64
-    q = torch.randn(pieces, B * K, inner, device=dev).to(torch.bfloat16)
+    q = torch.randn(pieces, B * K, inner, device=dev).to(DT)
     # layers > 1: every launch reads another layer's slice of a [pieces][layers] bank, as a decode step does (the whole bank is
     # 12 x 9.7 GB at the bench shape: no launch finds its pages where the previous one left the TLBs)
-    kbs = torch.randn(pieces, layers, B, H, S, 64, device=dev, dtype=torch.bfloat16)
-    vts = torch.randn(pieces, layers, B, H, S // 32, 64, 32, device=dev, dtype=torch.bfloat16)
+    kbs = torch.randn(pieces, layers, B, H, S, 64, device=dev, dtype=DT)
+    vts = torch.randn(pieces, layers, B, H, S // 32, 64, 32, device=dev, dtype=DT)
     kb, vt = kbs[:, 0], vts[:, 0]
     pstride = kbs[0].numel()
     lstride = kbs[0, 0].numel() * 2  # bytes
     it = [0]
     mask = torch.ones(B, S, dtype=torch.uint8, device=dev)
-    out = torch.empty(pieces, B * K, inner, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(B * K, pieces * inner, dtype=DT, device=dev)  # (two pieces: interleaved rows)
     st = torch.cuda.current_stream().cuda_stream
     bits = torch.zeros(B, 128, dtype=torch.int32, device=dev)
     _lib.check(lib.gram_mask_key_bits(mask.data_ptr(), bits.data_ptr(), B, S, st), "bits")
@@ -36,16 +37,16 @@ def one(pieces, B=4096, H=12, S=384, K=20, reps=20, use_bits=True, layers=1):
         ly = it[0] % layers
         it[0] += 1
         _lib.check(lib.gram_cross_attn_decode_split(q.data_ptr(), kbs.data_ptr() + ly * lstride, vts.data_ptr() + ly * lstride, mask.data_ptr(), out.data_ptr(), B, K, H, S,
-                                                    None, None, pieces, q[0].numel(), pstride, out[0].numel(), bits.data_ptr() if use_bits else None, st), "xattn")
+                                                    None, None, pieces, q[0].numel(), pstride, bits.data_ptr() if use_bits else None, st), "xattn")
     for _ in range(3):
         run()
     if os.environ.get("XA_HEAT"):
         # every timed launch right behind a large GEMM, as in a decode step (does the kernel see the clocks / power state the GEMMs
         # leave behind?): per-launch events, the GEMMs are not in the sum
         M, N_, K_ = 81920, 2304, 768
-        ga = torch.randn(M, K_, device=dev).to(torch.bfloat16)
-        gw = torch.randn(N_, K_, device=dev).to(torch.bfloat16)
-        gc = torch.empty(M, N_, dtype=torch.bfloat16, device=dev)
+        ga = torch.randn(M, K_, device=dev).to(DT)
+        gw = torch.randn(N_, K_, device=dev).to(DT)
+        gc = torch.empty(M, N_, dtype=DT, device=dev)
         ev = []
         for _ in range(reps):
             for _ in range(int(os.environ["XA_HEAT"])):

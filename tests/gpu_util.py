@@ -7,6 +7,8 @@ import torch
 from gram_amd import _lib
 
 DEV = "cuda:0"
+DT = _lib.piece_dtype()  # the library's 16-bit operand type: float16 (bfloat16 for the PIECE=bf16 build)
+F16 = DT == torch.float16
 
 
 def lib():
@@ -22,7 +24,32 @@ def p(t):
 
 
 def bf(t):
-    return t.to(DEV, torch.float32).to(torch.bfloat16).contiguous()
+    """fp32 -> the library's 16-bit type, on the device"""
+    return t.to(DEV, torch.float32).to(DT).contiguous()
+
+
+def pieces_of(x, s=2):
+    """[s][...] 16-bit pieces of an fp32 tensor (device): p_i = r16(x - p_0 - .. - p_{i-1})."""
+    r, out = x.float().clone(), []
+    for _ in range(s):
+        out.append(r.to(DT))
+        r = r - out[-1].float()
+    return torch.stack(out).contiguous()
+
+
+def inter(x):
+    """fp32 [rows][cols] -> the interleaved two-piece operand [rows][2 * cols] a GEMM reads (gram_hip.h)"""
+    return _lib.interleave(pieces_of(x, 2))
+
+
+def join(p):
+    """[s][...] planar pieces -> fp64 value"""
+    return p.double().sum(0)
+
+
+def join_inter(x):
+    """interleaved [rows][2 * cols] -> fp64 [rows][cols]"""
+    return _lib.deinterleave(x).double().sum(0)
 
 
 def gemm(A, W, epi, C_out=None, bank=None):

@@ -14,7 +14,8 @@ and inputs:
   * adjacent-pair order swaps as a function of the reference's score gap between the two items;
   * max |score difference| over sequences both sides returned.
 
-    python tests/precision_population.py --users 4096 --chunk 256 --modes bf16 --out gpurun_out/precision.json
+    python tests/precision_population.py --users 4096 --chunk 256 --modes f16x3,f16 --out gpurun_out/precision.json
+    python tests/precision_population.py --users 2048 --sweep f16x3      # every stage at one piece, the rest at two
 
 ``--sharpen F`` multiplies every attention q projection by F: at T5's random init the attention logits are ~N(0,1)
 and every query averages ~140 keys, which washes the encoder out of the scores (all users get nearly the same
@@ -142,8 +143,8 @@ def sweep_modes(base, pieces):
     return [base] + [f"{base}/{st}={n}" for st in _lib.STAGES for n in range(1, pieces)]
 
 
-def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("bf16",), seed=2023, sharpen=1.0, N=3, L=128, K=20,
-        dev="cuda:0", log=print, n_items=0):
+def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("f16x3",), seed=2023, sharpen=1.0, N=3, L=128, K=20,
+        dev="cuda:0", log=print, n_items=0, ragged=False):
     from gram_amd.utils import generation_trie as gt
     from oracle import gram_oracle as O
 
@@ -171,6 +172,12 @@ def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("bf1
         ids = torch.randint(2, vmax, (B, N, L), generator=g)
         ids[:, :, -1] = 1
         mask = torch.ones(B, N, L, dtype=torch.bool)
+        if ragged:  # Collator-shaped: valid lengths U[L/4, L] with EOS at the valid end, one passage in eight fully padded (never passage 0)
+            lens = torch.randint(L // 4, L + 1, (B, N), generator=g)
+            lens[:, 1:][torch.rand(B, N - 1, generator=g) < 0.125] = 0
+            mask = torch.arange(L)[None, None, :] < lens[:, :, None]
+            ids[torch.arange(B)[:, None], torch.arange(N)[None, :], (lens - 1).clamp(min=0)] = 1
+            ids[~mask] = 0
         t0 = time.perf_counter()
         ref = O.generate(sd, oc, ids.to(dev), mask.to(dev), max_length, ofn, K, K, 1.0)
         torch.cuda.synchronize()
@@ -197,7 +204,7 @@ def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("bf1
     model.set_stage_pieces(None)
     return {
         "population": {"backbone": backbone, "dataset": dataset, "items": len(cands), "users": users, "N": N, "L": L, "K": K,
-                       "seed": seed, "q_sharpen": sharpen, "gold_rank": "reference rank (user index mod 10)",
+                       "seed": seed, "q_sharpen": sharpen, "ragged_masks": bool(ragged), "gold_rank": "reference rank (user index mod 10)",
                        "reference": "oracle/gram_oracle.py run with torch fp32 tensors on the GPU (rocBLAS fp32), HF-4.26 search on the host"},
         "modes": {m: summarise(a) for m, a in accs.items()},
     }
@@ -209,7 +216,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=256)
     ap.add_argument("--backbone", default="t5-base")
     ap.add_argument("--dataset", default="Beauty")
-    ap.add_argument("--modes", default="bf16")
+    ap.add_argument("--modes", default="f16x3")
+    ap.add_argument("--ragged", action="store_true", help="ragged masks (valid lengths U[L/4, L], some passages fully padded)")
     ap.add_argument("--seed", type=int, default=2023)
     ap.add_argument("--sharpen", type=float, default=1.0)
     ap.add_argument("--beams", type=int, default=20)
@@ -220,7 +228,7 @@ def main():
     if a.sweep:
         import gram_amd
         modes = tuple(sweep_modes(a.sweep, gram_amd.GRAM._PIECES[a.sweep]))
-    res = run(a.users, a.chunk, a.backbone, a.dataset, modes, a.seed, a.sharpen, K=a.beams)
+    res = run(a.users, a.chunk, a.backbone, a.dataset, modes, a.seed, a.sharpen, K=a.beams, ragged=a.ragged)
     txt = json.dumps(res, indent=1)
     print(txt)
     if a.out:

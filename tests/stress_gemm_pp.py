@@ -27,18 +27,18 @@ def main():
         epi = rng.choice([_lib.EPI_BF16, _lib.EPI_BF16_RELU, _lib.EPI_F32_ADD, _lib.EPI_F32])
         fused = rng.random() < 0.6
         g = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
-        A = torch.randn(M, K, generator=g).to(G.DEV).to(torch.bfloat16)
-        W = (torch.randn(N, K, generator=g) * K ** -0.5).to(G.DEV).to(torch.bfloat16)
+        A = torch.randn(M, K, generator=g).to(G.DEV).to(G.DT)
+        W = (torch.randn(N, K, generator=g) * K ** -0.5).to(G.DEV).to(G.DT)
         rs = (torch.rand(M, generator=g) + 0.5).to(G.DEV)
         base = torch.randn(M, N, generator=g).to(G.DEV) if epi == _lib.EPI_F32_ADD else None
         f32 = epi in (_lib.EPI_F32_ADD, _lib.EPI_F32)
 
         def run(v):
             lib.gram_debug_set_gemm_variant(v)
-            C = base.clone() if base is not None else torch.zeros(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device=G.DEV)
+            C = base.clone() if base is not None else torch.zeros(M, N, dtype=torch.float32 if f32 else G.DT, device=G.DEV)
             extra = []
             if fused and epi == _lib.EPI_F32_ADD:
-                xb = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+                xb = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
                 ss = torch.zeros(M, N // 64, dtype=torch.float32, device=G.DEV)
                 nf = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
                 extra = [xb, ss]

@@ -26,13 +26,14 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_struct_sizes():
     lib = _lib.load()
-    assert lib.gram_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.gram_abi_version() == _lib.ABI_VERSION == 5
     # field layout sanity (pointer + int32 packing as in the C header)
     assert ctypes.sizeof(_lib.KVBank) == 48
     assert ctypes.sizeof(_lib.Trie) == 40
     assert ctypes.sizeof(_lib.BeamState) == 24 + 12 * 8
-    assert ctypes.sizeof(_lib.ModelDesc) == 48 + 7 * 8 + 15 * 8 + 8 + 16
-    assert ctypes.sizeof(_lib.Split) == 40
+    assert ctypes.sizeof(_lib.ModelDesc) == 48 + 7 * 8 + 15 * 8 + 8 + 16 + 8
+    assert ctypes.sizeof(_lib.Split) == 32
+    assert lib.gram_piece_format() in (0, 1)
 
 
 def test_argument_errors_without_gpu():

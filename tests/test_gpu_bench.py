@@ -31,7 +31,7 @@ def _run(cmd, env=None):
 def _check(r, n_gpus, steps):
     assert CONTRACT <= set(r)
     assert r["unit"] == "users/s" and r["n_gpus"] == n_gpus and r["steps"] == steps and r["higher_is_better"] is True
-    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "bf16x3" and r["data"] == "synthetic"
+    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f16x3" and r["data"] == "synthetic"
     assert "workload" in r["config"] and "model" not in r["config"]
     assert abs(r["value"] - n_gpus * 6 * steps / (r["ms_per_step"] * steps / 1e3)) < 1e-6 * r["value"]
     assert r["output_check"]["all_in_trie"] is True

@@ -12,7 +12,10 @@ import pytest
 import torch
 
 from oracle import gram_oracle as O
-from tests.test_gpu_path import DEV, _check_generate, _model
+from tests.test_gpu_path import DEV, F16, SCORE_TOL, _check_generate, _model
+
+# the library's precision modes: one 16-bit piece per value / two pieces (the default, fp32-class)
+ONE, TWO = ("f16", "f16x3") if F16 else ("bf16", "bf16x3")
 
 pytestmark = pytest.mark.gpu
 
@@ -74,7 +77,7 @@ def test_t5base_full_fusion_vs_oracle(gpu, dataset, N, L):
     ref = O.generate(sd, oc, ids, mask, max(len(c) for c in cands), O.prefix_allowed_tokens_fn(O.Trie(cands)), K, K, 1.0)
     out = _generate(m, ids, mask, cands, K)
     assert out["sequences"].shape == ref["sequences"].shape
-    _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=0.02)
+    _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=SCORE_TOL)
     agree = sum(int(torch.equal(a, b)) for a, b in zip(out["sequences"].cpu(), ref["sequences"]))
     print(f"\n[{dataset} N={N}] identical rank positions: {agree}/{K}; top-1 same: {torch.equal(out['sequences'][0].cpu(), ref['sequences'][0])}")
 
@@ -96,16 +99,17 @@ def test_t5large_beam50_yelp_vs_oracle(gpu):
     ref = O.generate(sd, oc, ids, mask, max(len(c) for c in cands), O.prefix_allowed_tokens_fn(O.Trie(cands)), K, K, 1.0)
     out = _generate(m, ids, mask, cands, K)
     assert out["sequences"].shape == ref["sequences"].shape
-    _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=0.02)
+    _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=SCORE_TOL)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", [ONE, TWO])
 def test_config5_full_shape_properties(gpu, precision):
     """configs[4] at its full shape -- T5-large, N = 21 passages (S = 2 688 fused keys, the long KV the config names),
     beam 50 (four 16-beam tiles in the cross-attention), the Yelp Trie, T = 11 -- too big for the CPU oracle, so checked
     through size-independent properties: every hypothesis is a Trie member, none repeats, scores are sorted and finite, a
-    user's result does not depend on the batch it is scored in, and (bf16x3) the scores agree with the plain bf16 run to
-    the bf16 tolerance."""
+    user's result does not depend on the batch it is scored in, and (two-piece mode) ONE user's sequences and scores against
+    the fp32 oracle arithmetic run with its tensors on the GPU (oracle/gram_oracle.py, plain torch fp32 ops: the CPU needs
+    minutes per user at this shape)."""
     from gram_amd import T5Config
     gc = T5Config.named("t5-large", max_item_num=20)
     torch.manual_seed(5)
@@ -127,17 +131,25 @@ def test_config5_full_shape_properties(gpu, precision):
     one = _generate(m, ids[1:2], mask[1:2], cands, K)
     assert torch.equal(one["sequences_scores"].cpu(), scores[K:2 * K])
     assert torch.equal(one["sequences"].cpu(), seqs[K:2 * K][:, : one["sequences"].shape[1]])
-    if precision == "bf16x3":
-        m.set_precision("bf16")
-        ref = _generate(m, ids, mask, cands, K)
+    if precision == TWO:
+        oc = O.OracleConfig.named("t5-large", max_item_num=20)
+        seen, sd_dev = {}, {}
+        for k_, v_ in m.state_dict().items():  # (aliases stay aliased)
+            sd_dev[k_] = seen.setdefault(v_.data_ptr(), v_.detach().to(DEV, torch.float32))
+        ref = O.generate(sd_dev, oc, ids[1:2].to(DEV), mask[1:2].to(DEV), max(len(c) for c in cands),
+                         O.prefix_allowed_tokens_fn(O.Trie(cands)), K, K, 1.0)
         rs, rq = ref["sequences_scores"].cpu(), ref["sequences"].cpu()
-        want = {(i // K, _strip(r)): float(v) for i, (r, v) in enumerate(zip(rq.tolist(), rs))}
-        shared = [abs(want[(i // K, _strip(r))] - float(v)) for i, (r, v) in enumerate(zip(seqs.tolist(), scores))
-                  if (i // K, _strip(r)) in want]
-        assert len(shared) > B * K // 2 and max(shared) < 0.03, (len(shared), max(shared))  # same items, bf16-level score differences
+        want = {_strip(r): float(v) for r, v in zip(rq.tolist(), rs)}
+        mine = [(_strip(r), float(v)) for r, v in zip(seqs[K:2 * K].tolist(), scores[K:2 * K])]
+        shared = [abs(want[r] - v) for r, v in mine if r in want]
+        same_order = sum(int(a[0] == _strip(b)) for a, b in zip(mine, rq.tolist()))
+        print(f"\n[config 5, one user vs the on-GPU fp32 oracle] shared {len(shared)}/{K}, same rank position {same_order}/{K}, "
+              f"max |score diff| {max(shared):.2e}")
+        # (near-ties at the K-th place may differ in membership; the scores of every shared item agree to the mode's tolerance)
+        assert len(shared) >= K - 2 and max(shared) < 1.5 * SCORE_TOL  # observed 2.9e-6 (24 + 24 layers), (len(shared), max(shared))
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", [ONE, TWO])
 def test_full_size_properties_and_batch_invariance(gpu, precision):
     """configs[1] at bench scale (B = 96 users, T5-base, Beauty Trie, beam 20): size-independent checks, in plain bf16 and in
     the headline arithmetic (the batches below go through the ping-pong, the 128-row and the skinny GEMM kernels)."""
@@ -203,7 +215,7 @@ def test_batch_invariance_other_backbones(gpu, backbone, B, N, K, dataset):
             assert torch.equal(o2["sequences_scores"][j * K:(j + 1) * K].cpu(), scores[u * K:(u + 1) * K]), u
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "bf16x6"])
+@pytest.mark.parametrize("precision", [ONE, TWO])
 def test_passage_compaction_is_result_neutral(gpu, monkeypatch, precision):
     """Ragged batch (users padded to N = 5 with fully masked passages): running the encoder on the active
     passages only gives bit-identical sequences and scores, and the padded bank positions are never read
@@ -226,7 +238,7 @@ def test_passage_compaction_is_result_neutral(gpu, monkeypatch, precision):
     assert torch.isfinite(comp["sequences_scores"]).all()
 
 
-@pytest.mark.parametrize("backbone,N,L,K,precision", [("small", 5, 64, 8, "bf16"), ("t5-base", 4, 96, 20, "bf16"), ("small", 5, 64, 8, "bf16x3")])
+@pytest.mark.parametrize("backbone,N,L,K,precision", [("small", 5, 64, 8, ONE), ("t5-base", 4, 96, 20, ONE), ("small", 5, 64, 8, TWO)])
 def test_passage_cache_is_result_neutral(gpu, backbone, N, L, K, precision):
     """SURVEY.md §8f N2: item passages drawn from a pool and registered with ``cache_passages`` skip the encoder;
     sequences and scores are bit-identical to encoding everything in place -- with a ragged batch (fully padded
@@ -354,10 +366,10 @@ def test_live_row_compaction_partial_steps(gpu):
     assert torch.equal(seq_live, seq_all) and torch.equal(sc_live, sc_all)
     assert n_live == n_all and work_live < 0.9 * work_all, (n_live, n_all, work_live, work_all)
     ref = O.generate(sd, oc, ids[:4], mask[:4], max(len(c) for c in cands), O.prefix_allowed_tokens_fn(O.Trie(cands)), K, K, 1.0)
-    _check_generate(oc, sd, dict(sequences=seq_live[: 4 * K], sequences_scores=sc_live[: 4 * K]), ref, ids[:4], mask[:4], cands, K, 0.02)
+    _check_generate(oc, sd, dict(sequences=seq_live[: 4 * K], sequences_scores=sc_live[: 4 * K]), ref, ids[:4], mask[:4], cands, K, SCORE_TOL)
 
 
-@pytest.mark.parametrize("dataset,K,precision", [("Beauty", 20, "bf16"), ("Toys", 8, "bf16"), ("Toys", 8, "bf16x3")])
+@pytest.mark.parametrize("dataset,K,precision", [("Beauty", 20, ONE), ("Toys", 8, ONE), ("Toys", 8, TWO)])
 def test_live_row_compaction_is_result_neutral(gpu, dataset, K, precision):
     """Last decode step(s) on the live rows only (gram_live_rows_t: beams that left the Trie at EOS are skipped) vs every
     row: bit-identical sequences and scores on the real item Tries (ids of l or l+1 pieces), and the compact step

@@ -32,7 +32,7 @@ def test_gemm_epilogues(G, M, N, K):
     from gram_amd import _lib
     A, W = G.bf(_r(M, K, seed=1)), G.bf(_r(N, K, seed=2, scale=K ** -0.5))
     ref = A.float() @ W.float().T
-    out = torch.empty(M, N, dtype=torch.bfloat16, device=G.DEV)
+    out = torch.empty(M, N, dtype=G.DT, device=G.DEV)
     G.gemm(A, W, _lib.EPI_BF16, out)
     # bf16 output rounding: 2^-8 relative
     assert torch.allclose(out.float(), ref, atol=2e-2, rtol=1e-2)
@@ -69,10 +69,10 @@ def test_gemm_persistent_variants(G, M, N, K):
             L_.gram_debug_set_gemm_variant(v)
             o = {}
             for epi in (_lib.EPI_BF16, _lib.EPI_BF16_RELU):
-                y = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+                y = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
                 G.gemm(A, W, epi, y)
                 o[("plain", epi)] = y
-                y2 = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+                y2 = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
                 cons = _lib.NormFusion(None, None, rs.data_ptr(), 0, K, 1e-6)  # nblk_in = 0: ss_in holds 1/rms per row
                 _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(y2), M, N, K, K, N, epi, None, ct.byref(cons), G.stream()), "consumer")
                 o[("scaled", epi)] = y2
@@ -80,7 +80,7 @@ def test_gemm_persistent_variants(G, M, N, K):
             G.gemm(A, W, _lib.EPI_F32, f)
             o["f32"] = f
             x = base.clone()
-            xb = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+            xb = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
             ss = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=G.DEV)
             prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
             _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(x), M, N, K, K, N, _lib.EPI_F32_ADD, None, ct.byref(prod), G.stream()), "producer")
@@ -95,7 +95,7 @@ def test_gemm_persistent_variants(G, M, N, K):
             assert torch.allclose(o[("scaled", epi)].float(), act(ref * rs[:, None]), atol=3e-2, rtol=1e-2), (v, epi)
         assert torch.allclose(o["f32"], ref, atol=1e-3, rtol=1e-4), v
         assert torch.allclose(o["add"], base + ref, atol=2e-3, rtol=1e-4), v
-        assert torch.equal(o["xb"], o["add"].to(torch.bfloat16)), v
+        assert torch.equal(o["xb"], o["add"].to(G.DT)), v
         assert torch.allclose(o["ss"].sum(-1), (o["add"] * o["add"]).sum(-1), rtol=1e-5), v
     for key in outs[3]:
         assert torch.equal(outs[3][key], outs[22][key]), key
@@ -122,10 +122,10 @@ def test_gemm_skinny_matches_tiled(G, M, N, K):
             L_.gram_debug_set_gemm_variant(v)
             o = {}
             for epi in (_lib.EPI_BF16, _lib.EPI_BF16_RELU):
-                y = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+                y = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
                 G.gemm(A, W, epi, y)
                 o[("plain", epi)] = y
-                y2 = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+                y2 = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
                 cons = _lib.NormFusion(None, None, ssin.data_ptr(), K // 64, K, 1e-6)
                 _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(y2), M, N, K, K, N, epi, None, ct.byref(cons), G.stream()), "consumer")
                 o[("scaled", epi)] = y2
@@ -133,7 +133,7 @@ def test_gemm_skinny_matches_tiled(G, M, N, K):
             G.gemm(A, W, _lib.EPI_F32, f)
             o["f32"] = f
             x = base.clone()
-            xb = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+            xb = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
             ss = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=G.DEV)
             prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
             _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(x), M, N, K, K, N, _lib.EPI_F32_ADD, None, ct.byref(prod), G.stream()), "producer")
@@ -174,12 +174,12 @@ def test_gemm_64_row_tiles_match_128(G, M, N, K):
         for v in (1, 31, 33, 34):
             L_.gram_debug_set_gemm_variant(v)
             o = {}
-            y = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+            y = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
             cons = _lib.NormFusion(None, None, ssin.data_ptr(), K // 64, K, 1e-6)
             _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(y), M, N, K, K, N, _lib.EPI_BF16_RELU, None, ct.byref(cons), G.stream()), "consumer")
             o["relu"] = y
             x = base.clone()
-            xb = torch.zeros(M, N, dtype=torch.bfloat16, device=G.DEV)
+            xb = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
             ss = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=G.DEV)
             prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
             _lib.check(L_.gram_gemm_bf16_ex(G.p(A), G.p(W), G.p(x), M, N, K, K, N, _lib.EPI_F32_ADD, None, ct.byref(prod), G.stream()), "producer")
@@ -214,8 +214,8 @@ def test_gemm_kv_bank(G):
     inner = H * 64
     A = G.bf(_r(B * S, d, seed=4))
     W = G.bf(_r(layers * 2 * inner, d, seed=5, scale=d ** -0.5))
-    k = torch.zeros(layers, B, H, S, 64, dtype=torch.bfloat16, device=G.DEV)
-    vt = torch.zeros(layers, B, H, S // 32, 64, 32, dtype=torch.bfloat16, device=G.DEV)  # V^T blocked by 32 keys
+    k = torch.zeros(layers, B, H, S, 64, dtype=G.DT, device=G.DEV)
+    vt = torch.zeros(layers, B, H, S // 32, 64, 32, dtype=G.DT, device=G.DEV)  # V^T blocked by 32 keys
     bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, B, H, S)
     G.gemm(A, W, _lib.EPI_KV_BANK, None, bank)
     ref = (A.float() @ W.float().T).view(B, S, layers, 2, H, 64)
@@ -254,8 +254,8 @@ def test_gemm_kv_bank_persistent(G, compact):
     try:
         for v in (3, 22):
             L_.gram_debug_set_gemm_variant(v)
-            k = torch.zeros(layers, B, H, S, 64, dtype=torch.bfloat16, device=G.DEV)
-            vt = torch.zeros(layers, B, H, S // 32, 64, 32, dtype=torch.bfloat16, device=G.DEV)
+            k = torch.zeros(layers, B, H, S, 64, dtype=G.DT, device=G.DEV)
+            vt = torch.zeros(layers, B, H, S // 32, 64, 32, dtype=G.DT, device=G.DEV)
             if compact:
                 pm = pmap.to(G.DEV)
                 bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, B, H, S, pm.data_ptr(), pN, pL)
@@ -300,7 +300,7 @@ def test_embed_rmsnorm_lse(G):
     xx = _r(rows, d, seed=8, scale=3.0).to(G.DEV)
     w = (1 + 0.1 * _r(d, seed=9)).to(G.DEV)
     pos = _r(N, d, seed=10, scale=0.02).to(G.DEV)
-    out = torch.empty(rows, d, dtype=torch.bfloat16, device=G.DEV)
+    out = torch.empty(rows, d, dtype=G.DT, device=G.DEV)
     _lib.check(L_.gram_rmsnorm_bf16(G.p(xx), G.p(w), G.p(out), rows, d, 1e-6, 0.5, G.p(pos), N, Lp, G.stream()), "rmsnorm")
     ref = O.rms_norm(xx.cpu(), w.cpu(), 1e-6) * 0.5 + pos.cpu()[(torch.arange(rows) // Lp) % N]
     assert torch.allclose(out.float().cpu(), ref, atol=1e-2, rtol=8e-3)  # bf16 output
@@ -330,7 +330,7 @@ def test_enc_self_attn(G, L):
         mask[p_, : int(torch.randint(1, L + 1, (1,), generator=g))] = True
     mask[P - 1] = False  # fully padded passage: reference gives uniform attention (all scores == finfo.min)
     mask[0] = True
-    out = torch.empty(P * L, inner, dtype=torch.bfloat16, device=G.DEV)
+    out = torch.empty(P * L, inner, dtype=G.DT, device=G.DEV)
     m8 = mask.to(G.DEV).view(torch.uint8).contiguous()
     _lib.check(G.lib().gram_enc_self_attn(G.p(qkv), G.p(bias), G.p(m8), G.p(out), P, L, H, G.stream()), "enc_attn")
     # oracle on the same bf16-rounded operands
@@ -361,7 +361,7 @@ def test_cross_attn_decode(G, K, S):
     mask[1, : S // 2] = False  # leading masked steps (whole 32-key steps of -min before any valid key)
     if S >= 64:
         mask[2, 32:] = False
-    out = torch.empty(B * K, inner, dtype=torch.bfloat16, device=G.DEV)
+    out = torch.empty(B * K, inner, dtype=G.DT, device=G.DEV)
     m8 = mask.to(G.DEV).view(torch.uint8).contiguous()
     _lib.check(G.lib().gram_cross_attn_decode(G.p(q), G.p(kb), G.p(vt), G.p(m8), G.p(out), B, K, H, S, G.stream()), "xattn")
     qh = q.float().cpu().view(B, K, H, 64).permute(0, 2, 1, 3)  # (B,H,K,64)
@@ -381,7 +381,7 @@ def test_cross_attn_all_masked_user(G):
     vb = torch.randn(B, H, S, 64, generator=g)
     vt = G.bf(G.vt_blocked(vb.transpose(2, 3).contiguous()))
     m8 = torch.zeros(B, S, dtype=torch.uint8, device=G.DEV)
-    out = torch.empty(B * K, 64, dtype=torch.bfloat16, device=G.DEV)
+    out = torch.empty(B * K, 64, dtype=G.DT, device=G.DEV)
     _lib.check(G.lib().gram_cross_attn_decode(G.p(q), G.p(kb), G.p(vt), G.p(m8), G.p(out), B, K, H, S, G.stream()), "xattn")
     ref = G.vt_unblocked(vt).float().cpu()[0, 0].mean(-1)  # uniform average over keys
     assert torch.allclose(out.float().cpu(), ref.expand(K, 64), atol=2e-2, rtol=2e-2)
@@ -396,14 +396,14 @@ def test_dec_self_attn(G):
     g = torch.Generator().manual_seed(21)
     table = torch.randn(32, H, generator=g) * 0.5
     bias = table[relative_position_bucket(-torch.arange(0, 32), False, 32, 128)].t().contiguous().to(G.DEV)
-    kc = torch.zeros(Tmax, R, inner, dtype=torch.bfloat16, device=G.DEV)
+    kc = torch.zeros(Tmax, R, inner, dtype=G.DT, device=G.DEV)
     vc = torch.zeros_like(kc)
     anc = torch.arange(R, dtype=torch.int32).repeat(Tmax, 1).to(G.DEV)
     cfg = O.OracleConfig(num_heads=H)
     ks, vs = None, None
     for t in range(6):
         qkv = G.bf(torch.randn(R, 3 * inner, generator=g) * 0.5)
-        out = torch.empty(R, inner, dtype=torch.bfloat16, device=G.DEV)
+        out = torch.empty(R, inner, dtype=G.DT, device=G.DEV)
         _lib.check(G.lib().gram_dec_self_attn(G.p(qkv), G.p(kc), G.p(vc), G.p(anc), G.p(bias), G.p(out), R, H, t, Tmax, G.stream()),
                    "dec_attn")
         x = qkv.float().cpu().view(R, 1, 3, H, 64)
@@ -616,19 +616,19 @@ def test_folded_layernorm_gemms(G, M):
     Wo = G.bf(torch.randn(d, d, generator=g) * d ** -0.5)
     gain = (1 + 0.1 * torch.randn(d, generator=g)).to(G.DEV)
     Wi = torch.randn(F, d, generator=g).to(G.DEV) * d ** -0.5
-    Wi_folded = (Wi * gain[None, :]).to(torch.bfloat16).contiguous()
+    Wi_folded = (Wi * gain[None, :]).to(G.DT).contiguous()
     x = x0.clone()
-    xb = torch.zeros(M, d, dtype=torch.bfloat16, device=G.DEV)
+    xb = torch.zeros(M, d, dtype=G.DT, device=G.DEV)
     ss = torch.full((M, d // 64), float("nan"), dtype=torch.float32, device=G.DEV)
     L_ = G.lib()
     prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
     _lib.check(L_.gram_gemm_bf16_ex(G.p(a), G.p(Wo), G.p(x), M, d, d, d, d, _lib.EPI_F32_ADD, None, C.byref(prod), G.stream()), "producer")
     x_ref = x0 + a.float() @ Wo.float().T
     assert torch.allclose(x, x_ref, atol=2e-3, rtol=1e-4)
-    assert torch.equal(xb, x.to(torch.bfloat16))
+    assert torch.equal(xb, x.to(G.DT))
     assert torch.allclose(ss.sum(-1), (x * x).sum(-1), rtol=1e-5)
     for epi, act in ((_lib.EPI_BF16, lambda t: t), (_lib.EPI_BF16_RELU, lambda t: t.clamp(min=0))):
-        y = torch.empty(M, F, dtype=torch.bfloat16, device=G.DEV)
+        y = torch.empty(M, F, dtype=G.DT, device=G.DEV)
         cons = _lib.NormFusion(None, None, ss.data_ptr(), d // 64, d, 1e-6)
         _lib.check(L_.gram_gemm_bf16_ex(G.p(xb), G.p(Wi_folded), G.p(y), M, F, d, d, F, epi, None, C.byref(cons), G.stream()), "consumer")
         ref = act(O.rms_norm(x.cpu(), gain.cpu(), 1e-6) @ Wi.cpu().T)
@@ -641,8 +641,8 @@ def test_folded_layernorm_gemms(G, M):
     table = torch.randn(V, d, generator=g).to(G.DEV)
     ids = torch.randint(0, V, (77,), generator=g).to(G.DEV)
     xe = torch.empty(77, d, device=G.DEV)
-    xbe = torch.empty(77, d, dtype=torch.bfloat16, device=G.DEV)
+    xbe = torch.empty(77, d, dtype=G.DT, device=G.DEV)
     sse = torch.empty(77, d // 64, device=G.DEV)
     _lib.check(L_.gram_embed_ex(G.p(table), G.p(ids), 1, G.p(xe), G.p(xbe), G.p(sse), d // 64, 77, d, G.stream()), "embed_ex")
-    assert torch.equal(xe, table[ids]) and torch.equal(xbe, table[ids].to(torch.bfloat16))
+    assert torch.equal(xe, table[ids]) and torch.equal(xbe, table[ids].to(G.DT))
     assert torch.allclose(sse.sum(-1), (xe * xe).sum(-1), rtol=1e-5) and bool((sse[:, 1:] == 0).all())

@@ -114,7 +114,7 @@ def _rccl_worker(rdzv, ckpt, q):
     dist.init_process_group("nccl", init_method=f"file://{rdzv}", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
         got = all_gather_hit_ranks(np.array([3, -1, 0, 7], dtype=np.int16), torch.device(DEV))
-        args = fixture_args(eval_batch_size=4, rank=0)
+        args = fixture_args(eval_batch_size=4, rank=0, eval_check_allreduce=1)  # (the reference's all_reduce cross-check over RCCL too)
         model = gram_amd.create_model("gram", _cfg()).to(DEV)
         runner = get_runner("distributed", model, None, PieceTokenizer(), None, None, None, DEV, args, 0)
         runner.test(ckpt)

@@ -229,3 +229,39 @@ def test_dropin_launcher_resolves_bare_names_to_gram_amd(tmp_path):
     assert out.returncode == 0, out.stderr
     assert "gram_amd.runner gram_amd.model reference arguments module ['--datasets', 'Beauty']" in out.stdout
     assert "ValueError Unknown runner type: nope" in out.stdout
+
+
+def test_interleaved_two_piece_layout():
+    """gram_hip.h: a two-piece GEMM operand is [rows][cols / 32][2][32] -- element (n, piece p) of a row sits at
+    (n / 32) * 64 + p * 32 + n % 32 -- and ``_lib.deinterleave`` inverts ``_lib.interleave``."""
+    from gram_amd import _lib
+    rows, cols = 5, 96
+    p0 = torch.arange(rows * cols, dtype=torch.float32).view(rows, cols)
+    pieces = torch.stack([p0, -p0 - 1])
+    x = _lib.interleave(pieces)
+    assert x.shape == (rows, 2 * cols)
+    for n in (0, 1, 31, 32, 63, 64, 95):
+        for p in (0, 1):
+            assert torch.equal(x[:, (n // 32) * 64 + p * 32 + n % 32], pieces[p][:, n]), (n, p)
+    assert torch.equal(_lib.deinterleave(x), pieces)
+
+
+def test_runner_refuses_id_types_decoded_with_max_length_50():
+    """single_runner_gram.py:633-641 decodes every id type but 't5_token' / 'split' with max_length = 50, which the kernels (32 steps)
+    do not reproduce: refused, not approximated."""
+    from types import SimpleNamespace
+    import pytest
+    from gram_amd.runner import SingleRunnerGRAM
+
+    class Tok:
+        def encode(self, s):
+            return [5, 6, 1]
+
+    args = SimpleNamespace(metrics="hit@1", beam_size=1, item_id_type="other")
+    r = SingleRunnerGRAM(torch.nn.Linear(1, 1), None, Tok(), None, None, None, "cpu", args)
+    loader = []
+
+    class L(list):
+        dataset = SimpleNamespace(all_items=["a b"], dataset="D", task="t")
+    with pytest.raises(NotImplementedError):
+        r._score_loader(L(loader))
