@@ -43,6 +43,16 @@ namespace {
 #ifndef GRAM_PP_RES_NT
 #define GRAM_PP_RES_NT 0  // A/B build hook: the ping-pong kernel's residual read with the nt hint
 #endif
+// Ablation builds of the ping-pong kernel (`make ABL=n` -> libgram_hip_abl<n>.so, loaded by tests/bench_gemm_x3.py through GRAM_LIB;
+// the product library is built with 0 and contains none of it).  Bits: 1 = no tile-end epilogue (results wrong), 2 = no operand DMA
+// after the prologue, 4 = no LDS fragment reads after the prologue, 8 = in-kernel clock stamps, 16 = the tile-end epilogue without its
+// global stores (fp32: without the stores, the bf16 copy and the partials; the residual loads stay).
+#ifndef GRAM_PP_ABL
+#define GRAM_PP_ABL 0
+#endif
+#if GRAM_PP_ABL & 8  // + in-kernel clock stamps (MI355X_MICROARCH.md, DVFS item 6): per workgroup (shader cycles, 100-MHz ticks) around the tile loop
+__device__ unsigned long long g_pp_stamps[2 * 1024];
+#endif
 constexpr int BN = 128, BK = 64;
 
 enum { V_DMA_M64 = 31, V_DMA = 1, V_DMA_M256 = 3, V_PP = 22, V_RING_M64 = 33, V_RING_M128 = 34 };  // (ids kept from the variant table of round 1)
@@ -982,7 +992,8 @@ __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, c
           const int mr = j * 16 + row;
           // planar: the piece's 128-B row segment; interleaved: its two 64-B halves, side by side with the other piece's
           const uint32_t coff = o.inter ? (uint32_t)((c >> 2) * 128 + pc * 64 + (c & 3) * 16) : (uint32_t)(c * 16);
-          if (FULL || mr < o.rows) store16(o.c + (o.inter ? 0 : pc * o.c_ps_b) + ((uint32_t)mr * o.ldc_b + coff), val, o.nt);
+          if ((FULL || mr < o.rows) && (!(GRAM_PP_ABL & 16) || o.rows < -12345))  // (ablation bit 16: everything but the global stores)
+            store16(o.c + (o.inter ? 0 : pc * o.c_ps_b) + ((uint32_t)mr * o.ldc_b + coff), val, o.nt);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -1066,7 +1077,7 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
         f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16)) * o.scale;
         const int mr = j * 16 + row;
         float ssq = 0.f;
-        if (mr < o.rows) {
+        if (mr < o.rows && (!(GRAM_PP_ABL & 16) || o.rows < -12345)) {
           f32x4* pc = reinterpret_cast<f32x4*>(o.c + ((uint32_t)mr * o.ldc_b + c * 16));
           if constexpr (EPI == GRAM_EPI_F32_ADD) val += res[p * 4 + it];
           *pc = val;
@@ -1218,7 +1229,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       set_offsets();
     }
   };
+  bool abl_loop = false;  // (ablation builds only: the main loop has begun)
   auto issue = [&](int t, int par) {  // this wave's 2 DMA instructions of half-tile (cursor, type t) -> buffer (par, t)
+    if ((GRAM_PP_ABL & 2) && abl_loop) return;
     {
       const uint32_t dst = wave_lds + (par * 4 + t) * HT;
       if (t == 0 || t == 3) {
@@ -1246,6 +1259,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   const char* const a_base[2] = {smem + swz(wr * 64 + r16, g), smem + swz(wr * 64 + r16, 4 + g)};
   const char* const w_base[2] = {smem + swz(wc * 32 + r16, g), smem + swz(wc * 32 + r16, 4 + g)};
   auto read_a = [&](int par, int mq) {
+    if ((GRAM_PP_ABL & 4) && abl_loop) return;
     {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -1255,6 +1269,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     }
   };
   auto read_w = [&](int par, int nq) {
+    if ((GRAM_PP_ABL & 4) && abl_loop) return;
     {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -1494,8 +1509,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   //   ... W_nf(kk) [read in the previous k-tile's p3] | A_m0(kk) p0 | W_ns(kk) p1 | A_m1(kk) p2 | W_nf(kk+1) p3 | ...
   // Phase P issues the half-tile consumed in phase P + 7 (all of stream k-tile kk+2) into the buffer whose only
   // reading phase was P - 1, and then waits for all but its 6 newest half-tiles.
-  if (stagger > 0) {  // de-synchronise the CUs' store phases
-    const int units = ((slot & 7) * stagger * nkt) >> 3;
+  if (stagger > 0) {  // de-synchronise the store phases: CU by CU inside an XCD, or (bit 15) XCD by XCD with each XCD's CUs in step
+    const int ph = (stagger & 0x8000) ? xcd : (slot & 7);
+    stagger &= 0x7fff;
+    const int units = (ph * stagger * nkt) >> 3;
     for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);  // 512 cycles
   }
   // ---- prologue: everything phases -8 .. -1 would have issued = all of stream k-tiles 0 and 1
@@ -1565,6 +1582,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   bool pending = false;  // the m1 half of the previous tile is still in the accumulators
   zero_half(0);
   zero_half(1);
+  abl_loop = true;
+#if GRAM_PP_ABL & 8
+  const unsigned long long abl_t0 = __builtin_amdgcn_s_memtime(), abl_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   while (true) {
     {
       int mt, nr;
@@ -1638,7 +1659,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       // 256x128-tile kernel): inside the slots its residual loads drain the in-order DMA queue four times per tile and
       // group; here once.  Group 0 waits for group 1's last MFMA slot, both store, and group 1 falls one barrier behind again.
       if (wr == 0) pp_barrier();
-      if constexpr (LSE) {
+      if constexpr ((GRAM_PP_ABL & 1) != 0) {  // ablation: keep the accumulators live, store (almost) never
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        if (t == 12345.678f) reinterpret_cast<float*>(ep.C ? ep.C : ep.lse_part ? (void*)ep.lse_part : (void*)ep.bank_k)[lane] = t;
+      } else if constexpr (LSE) {
         // per row and 64-column block (= this wave's columns) the pair (max, sum exp(x - max)), reduced in exactly the
         // order of the 128-row kernels' epilogue, so a user's scores do not depend on which kernel its batch size selects
         const int blk = (n0 + wc * 64) >> 6;
@@ -1736,6 +1764,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     if (!more) break;
     tile += G;
   }
+#if GRAM_PP_ABL & 8
+  if (tid == 0 && blockIdx.x < 1024) {
+    g_pp_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - abl_t0;
+    g_pp_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - abl_r0;
+  }
+#endif
   // The last tile's m1 half is still in the accumulators.  Every DMA of this workgroup must have landed before it
   // ends, and after that the half-tile buffers are dead: they serve as 8 private patches for the final stores.
   if constexpr (!TEND) {
@@ -1813,7 +1847,8 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     static const int nt7 = getenv("GRAM_GEMM_NT7") ? atoi(getenv("GRAM_GEMM_NT7")) : 0;  // A/B hook: streaming stores of the tile-end bf16 rows (measured: no gain)
     if (nt7) ep.nt |= 8;
     static const int stagger_env = getenv("GRAM_GEMM_STAGGER") ? atoi(getenv("GRAM_GEMM_STAGGER")) : -1;
-    const int stagger = stagger_env >= 0 ? stagger_env : g_stagger;
+    static const int stagger_xcd = getenv("GRAM_GEMM_STAGGER_XCD") ? atoi(getenv("GRAM_GEMM_STAGGER_XCD")) : 0;  // phase = XCD instead of slot & 7
+    const int stagger = (stagger_env >= 0 ? stagger_env : g_stagger) | (stagger_xcd ? 0x8000 : 0);
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, X3>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda,
                        ep, ntiles, (stagger & 0xffff) | (gm << 16));
     GRAM_CHECK_LAUNCH();
@@ -1924,6 +1959,22 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
 }
 
 }  // namespace
+
+#if GRAM_PP_ABL & 8
+// (ablation builds only, not part of the C ABI) the last ping-pong launch's in-kernel clock: out[0] = median GHz over its workgroups
+extern "C" int gram_debug_pp_clock(double* out, int nblocks) {
+  static unsigned long long h[2 * 1024];
+  if (nblocks < 1 || nblocks > 1024 || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pp_stamps), sizeof(h)) != hipSuccess) return GRAM_E_ARG;
+  double v[1024];
+  for (int i = 0; i < nblocks; ++i) v[i] = h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] * 0.1 : 0.0;
+  for (int i = 1; i < nblocks; ++i)
+    for (int j = i; j > 0 && v[j] < v[j - 1]; --j) { const double t = v[j]; v[j] = v[j - 1]; v[j - 1] = t; }
+  out[0] = v[nblocks / 2];
+  out[1] = v[0];
+  out[2] = v[nblocks - 1];
+  return 0;
+}
+#endif
 
 extern "C" int gram_gemm_stream_max_m(void) { return g_force_variant < 0 ? stream_max_m() : 0; }
 
