@@ -1083,13 +1083,23 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
           *pc = val;
           if constexpr (EPI == GRAM_EPI_F32_ADD) {
             if (o.xb) {
-              f32x4 rem = val;
-              for (int pc = 0; pc < o.split; ++pc) {
-                const uint2 pk = pack_bf16x4(rem);
-                // (split == 2: interleaved -- lanes 0..7 hold block 0 of the wave's 64 columns, lanes 8..15 block 1)
-                const uint32_t xoff = o.split == 2 ? (uint32_t)((c >> 3) * 128 + pc * 64 + (c & 7) * 8) : (uint32_t)(c * 8);
-                *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + xoff)) = pk;
-                rem -= unpack_bf16x4(pk);
+              if (o.split == 2) {
+                // interleaved copy (lanes 0..7 hold block 0 of the wave's 64 columns, lanes 8..15 block 1; a block = piece 0's 64 B, then
+                // piece 1's): lanes c and c ^ 1 swap one piece each, so that the even lane stores 16 B of piece 0 (columns 4c .. 4c + 7)
+                // and the odd lane 16 B of piece 1 -- one 16-B store per lane instead of two 8-B ones (the tile-end store tail is bound by
+                // its instruction count: an 8-B-per-lane store costs as much as a 16-B one)
+                const uint2 p0 = pack_bf16x4(val);
+                const uint2 p1 = pack_bf16x4(val - unpack_bf16x4(p0));
+                const bool odd = c & 1;
+                const uint2 send = odd ? p0 : p1;
+                uint2 recv;
+                recv.x = (uint32_t)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]: lane ^ 1
+                recv.y = (uint32_t)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xF, 0xF, true);
+                const uint4 out = odd ? make_uint4(recv.x, recv.y, p1.x, p1.y) : make_uint4(p0.x, p0.y, recv.x, recv.y);
+                const uint32_t xoff = (uint32_t)((c >> 3) * 128 + (odd ? 64 : 0) + ((c & 6) * 8));
+                *reinterpret_cast<uint4*>(o.xb + ((uint32_t)mr * o.ldx_b + xoff)) = out;
+              } else {
+                *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + (uint32_t)(c * 8))) = pack_bf16x4(val);
               }
               ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
             }
@@ -1103,11 +1113,12 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
           for (int sh = 1; sh < 16; sh <<= 1)
 #pragma unroll
             for (int it = 0; it < 4; ++it) ssq4[it] += __shfl_xor(ssq4[it], sh, 64);
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int mr = j * 16 + it * 4 + (lane >> 4);
-            if ((lane & 15) == 0 && mr < o.rows) o.ss[(uint32_t)mr * o.ss_nblk] = ssq4[it];
-          }
+          // after the butterfly every lane of a row holds the row's sum: lane c < 4 stores the partial of pass c's row -- one store
+          // instruction with 16 active lanes instead of four with 4 each
+          const int cc = lane & 15;
+          const float mine = cc == 0 ? ssq4[0] : cc == 1 ? ssq4[1] : cc == 2 ? ssq4[2] : ssq4[3];
+          const int mr = j * 16 + cc * 4 + (lane >> 4);
+          if (cc < 4 && mr < o.rows) o.ss[(uint32_t)mr * o.ss_nblk] = mine;
         }
       }
       __builtin_amdgcn_wave_barrier();
