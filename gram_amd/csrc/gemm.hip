@@ -50,6 +50,12 @@ namespace {
 #ifndef GRAM_PP_ABL
 #define GRAM_PP_ABL 0
 #endif
+#ifndef GRAM_PP_PASS_PRIO
+#define GRAM_PP_PASS_PRIO 2  // A/B build hook: wave priority of the in-load-slot epilogue's passes (the MFMA slots run at 1)
+#endif
+#ifndef GRAM_PP_INSL
+#define GRAM_PP_INSL 0  // A/B build hook: 1 = two-piece 16-bit outputs from inside the pipeline (measured: no gain, profiles/r03h, r03i)
+#endif
 #if GRAM_PP_ABL & 8  // + in-kernel clock stamps (MI355X_MICROARCH.md, DVFS item 6): per workgroup (shader cycles, 100-MHz ticks) around the tile loop
 __device__ unsigned long long g_pp_stamps[2 * 1024];
 #endif
@@ -953,6 +959,8 @@ struct PPOut {
   bool inter;           // bf16 C interleaved (c = C + (m_first * ldc + 2 * n_first) * 2, ldc_b the physical row stride); xb always is when split == 2
   bool nt;              // streaming (nt) stores for the bf16 rows (A/B hook GRAM_GEMM_NT7)
   float scale;          // EpiArgs.out_scale
+  long q_ps;            // in-load-slot epilogue: bytes from piece 0 to piece 1 of a quadrant's row segment (interleaved C: 64)
+  uint32_t q_step;      // ... and from the n0 quadrants' segment to the n1 quadrants' (interleaved C: 128, planar: 64)
 };
 template <int EPI, bool FULL>
 __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, char* patch, const PPOut& o, int lane_, const float* rs) {
@@ -1151,8 +1159,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   // loads out of the DMA queue's way) and every X3 output (two pieces per value: a store count the in-slot jobs' counted waits do
   // not cover; with 1.5x the MFMAs per k-tile the tile-end placement costs less than it does in the plain kernel, where in-slot
   // bf16 stores measured 1 105 vs 1 035 TFLOP/s on the encoder QKV shape)
-  constexpr bool TEND = (EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD) || LSE || X3;
-  constexpr int RS_OFF = 8 * HT + 4 * 4096;  // bf16 epilogues: 2 x 1 KiB of row scales behind the patches
+  // INSL: the two-piece 16-bit outputs (QKV, FFN-in) leave from INSIDE the pipeline, in the LOAD slots around the tile boundary -- see
+  // "in-load-slot epilogue" below.  (GRAM_PP_INSL=0: A/B build with the tile-end epilogue.)
+  constexpr bool INSL = GRAM_PP_INSL && X3 && (EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU);
+  constexpr bool TEND = (EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD) || LSE || (X3 && !INSL);
+  constexpr int PATCHB = INSL ? 6144 : 4096;   // bytes of a patch shared by waves w and w + 4 (INSL: three 2-KiB passes in flight)
+  constexpr int RS_OFF = 8 * HT + 4 * PATCHB;  // bf16 epilogues: 2 x 1 KiB of row scales behind the patches
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 8 half-tile buffers + epilogue patches (+ row scales)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1177,8 +1189,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);  // this wave's 2 pieces (16 rows) of a half-tile
   const char* const Ab = reinterpret_cast<const char*>(A);
   const char* const Wb = reinterpret_cast<const char*>(W);
-  char* const patch = smem + 8 * HT + (F32OUT ? wave * PATCH : TEND ? wave * 2048 : (wave & 3) * PATCH);
+  char* const patch = smem + 8 * HT + (F32OUT ? wave * PATCH : TEND ? wave * 2048 : (wave & 3) * PATCHB);
   const bool has_rs = !F32OUT && ep.ss_in != nullptr;  // ss_nblk == 0 (1/rms per row), checked by the launcher
+  if constexpr (INSL) {  // its passes always multiply by a row scale from the RS area: all ones for a GEMM without (published by the prologue's barrier)
+    if (!has_rs) reinterpret_cast<float*>(smem + RS_OFF)[tid] = 1.f;
+  }
 
   // tile index -> (m-tile, n-tile column).  gm <= 1: n fastest.  gm > 1: groups of gm m-tiles, m fastest inside a group, so
   // that the 32 tiles an XCD works on at a time cover gm m-tiles x 32/gm n-tiles (fewer distinct A + W panels per round).
@@ -1509,6 +1524,130 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     __builtin_amdgcn_sched_barrier(0);
     pp_barrier();
   };
+  // ---- in-load-slot epilogue (INSL).  The tile-end epilogue of a two-piece 16-bit output costs 13-14 % of these GEMMs (both wave
+  // groups stop, 32 KiB per wave through a 2-KiB patch, then 256 KiB per CU through a vector-store path that moves ~32 B/clk; nothing of
+  // it overlaps an MFMA: profiles/r03d, r03f).  Here a quadrant's results leave in "passes" -- one m-tile (16 rows) x the quadrant's 32
+  // columns x both pieces: scale / ReLU / split, 4 ds_write_b64 into a 2-KiB patch laid out [16 rows][piece 0: 64 B | piece 1: 64 B]
+  // (for an interleaved output that IS the row's 128 B), 2 ds_read_b128, 2 row-contiguous 1-KiB stores -- placed in the LOAD slots
+  // between the quadrant's last MFMA slot of this tile and its first of the next one, where the wave otherwise waits for its SIMD
+  // partner's MFMA slot.  With the quadrant order of the last (odd) k-tile 01 00 10 11 and of the next tile's first (even) 00 01 11 10:
+  //   load slot before   | O:00   | O:10    | O:11        || E:00        | E:01        | E:11    | E:10
+  //   passes (quadrant.j)| 01.0 1 | 01.2 00.0| 01.3 00.1 2 || 00.3 11.0 10.0| 11.1 2 10.1 | 11.3 10.2| 10.3
+  // A quadrant is zeroed behind its last pass.  The patch is the 4 KiB waves w and w + 4 share (they are never in a load slot at the
+  // same time).  Stores count in vmcnt with the DMAs, in issue order: the counted wait of a load slot adds the stores of the last six
+  // load slots (exact for a wave whose 128 rows all exist; a partial wave counts none, which only makes its waits stricter).
+  // Extra stores in flight at the end of each load slot (sum over the last six load slots, the slot's own included), by position:
+  //   pairs of MODE 1 (first pair behind a tile of a full wave):  even k-tile 20 26 30 26, odd k-tile 22 16 10 4
+  //     (previous pair's last three slots 4 + 4 + 6, then 6 6 4 0: the single pass of the fourth slot is left out of the count)
+  //   pairs of MODE 2 (last pair of a tile of a full wave):       odd k-tile 0 4 8 14
+  auto end_load_slot_st = [&](bool full, auto Nc) {  // N = that sum for a full wave (a partial wave counts none of its stores)
+    constexpr int N = decltype(Nc)::value;
+    static_assert(N >= 0 && 12 + N <= 63, "vmcnt is a 6-bit count");
+    if constexpr ((GRAM_PP_ABL & 1) != 0) full = false;
+    if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    pp_barrier();
+  };
+  // up to three passes as ONE straight-line group (no branch between them: a basic-block boundary makes hipcc drain lgkmcnt): all splits
+  // and patch writes, then all patch reads, then the stores as their data arrives.  P = mq * 8 + nq * 4 + j-in-quadrant, -1 = none;
+  // pass u uses the 2 KiB at pt + 2048 u.  rs always points at row scales (all 1.0 when the GEMM has none: see the RS area's fill).
+  auto passes = [&](const PPOut& o, const float* rs, char* pt, auto P0c, auto P1c, auto P2c) {
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>;
+    if constexpr ((GRAM_PP_ABL & 1) != 0) {  // ablation: keep the accumulators live, store (almost) never
+      auto keep = [&](auto Pc) {
+        constexpr int P = decltype(Pc)::value;
+        if constexpr (P >= 0) {
+          constexpr int nq = (P >> 2) & 1, j = (P >> 3) * 4 + (P & 3);
+          const f32x4 t4 = acc[nq * 2][j] + acc[nq * 2 + 1][j];
+          const float t = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+          if (t == 12345.678f) reinterpret_cast<float*>(ep.C)[lane] = t;
+        }
+      };
+      keep(P0c);
+      keep(P1c);
+      keep(P2c);
+      return;
+    }
+    // The SIMD partner is in its MFMA slot at priority 1: at priority 0 this wave's ~45 vector instructions per pass would only issue
+    // once the partner has run out of MFMAs (MI355X_MICROARCH.md, "Two waves per SIMD", item 2), i.e. behind the slot instead of beside it
+    __builtin_amdgcn_s_setprio(GRAM_PP_PASS_PRIO);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // opaque: the lane constants are recomputed here, not kept live (or spilled) across the k-loop
+    const int lr = ln & 15, lg = ln >> 4;
+    // patch row lr: logical 16-B chunk piece * 4 + n-tile * 2 + (lg >> 1) at chunk ^ (lr & 7), 8-B half lg & 1
+    char* const wb = pt + lr * 128 + (lg & 1) * 8;
+    const int sw = lr & 7, gh = lg >> 1;
+    auto split_write = [&](auto Uc, auto Pc) {
+      constexpr int u = decltype(Uc)::value, P = decltype(Pc)::value;
+      if constexpr (P >= 0) {
+        constexpr int nq = (P >> 2) & 1, j = (P >> 3) * 4 + (P & 3);
+        const float sc = rs[j * 16 + lr] * o.scale;
+        f32x4 v0 = acc[nq * 2][j] * sc, v1 = acc[nq * 2 + 1][j] * sc;
+        // (the ROUNDED products are what is split into pieces, as in every other kernel: keep hipcc from contracting acc * sc - hi into an fma)
+        asm volatile("" : "+v"(v0), "+v"(v1));
+        if constexpr (EPI == GRAM_EPI_BF16_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0[e] = fmaxf(v0[e], 0.f);
+            v1[e] = fmaxf(v1[e], 0.f);
+          }
+        }
+        const uint2 h0 = pack_bf16x4(v0), h1 = pack_bf16x4(v1);
+        const uint2 l0 = pack_bf16x4(v0 - unpack_bf16x4(h0)), l1 = pack_bf16x4(v1 - unpack_bf16x4(h1));
+        *reinterpret_cast<uint2*>(wb + u * 2048 + (((0 + gh) ^ sw) << 4)) = h0;
+        *reinterpret_cast<uint2*>(wb + u * 2048 + (((2 + gh) ^ sw) << 4)) = h1;
+        *reinterpret_cast<uint2*>(wb + u * 2048 + (((4 + gh) ^ sw) << 4)) = l0;
+        *reinterpret_cast<uint2*>(wb + u * 2048 + (((6 + gh) ^ sw) << 4)) = l1;
+      }
+    };
+    split_write(U0{}, P0c);
+    split_write(U1{}, P1c);
+    split_write(U2{}, P2c);
+    __builtin_amdgcn_wave_barrier();
+    const int row = ln >> 3, c = ln & 7;
+    const char* const gb = pt + row * 128 + ((c ^ (row & 7)) << 4);
+    uint4 val[3][2];
+    auto read_back = [&](auto Uc, auto Pc) {
+      constexpr int u = decltype(Uc)::value;
+      if constexpr (decltype(Pc)::value >= 0) {
+        val[u][0] = *reinterpret_cast<const uint4*>(gb + u * 2048);
+        val[u][1] = *reinterpret_cast<const uint4*>(gb + u * 2048 + 1024);
+      }
+    };
+    read_back(U0{}, P0c);
+    read_back(U1{}, P1c);
+    read_back(U2{}, P2c);
+    // a quadrant's 32 columns of a row: chunks 0..3 = piece 0 (64 B), 4..7 = piece 1, `o.q_ps` bytes further (interleaved C: 64, i.e. the
+    // row's 128 contiguous bytes; planar C: the piece stride); the n1 quadrants `o.q_step` bytes further (128 / 64)
+    char* const cb = o.c + ((c & 3) * 16 + (c >> 2) * o.q_ps);
+    auto store_rows = [&](auto Uc, auto Pc) {
+      constexpr int u = decltype(Uc)::value, P = decltype(Pc)::value;
+      if constexpr (P >= 0) {
+        constexpr int nq = (P >> 2) & 1, j = (P >> 3) * 4 + (P & 3);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int mr = j * 16 + it * 8 + row;
+          if (mr < o.rows && (!(GRAM_PP_ABL & 16) || o.rows < -12345))  // (ablation bit 16: everything but the global stores)
+            *reinterpret_cast<uint4*>(cb + ((uint32_t)mr * o.ldc_b + (uint32_t)nq * o.q_step)) = val[u][it];
+        }
+      }
+    };
+    store_rows(U0{}, P0c);
+    store_rows(U1{}, P1c);
+    store_rows(U2{}, P2c);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto zero_q = [&](int mq, int nq) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[nq * 2 + i][mq * 4 + j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
   auto zero_half = [&](int mq) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1566,6 +1705,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     o.c_ps_b = ep.c_pstride * 2;
     o.nt = (ep.nt & 8) != 0;
     o.scale = ep.out_scale;
+    o.q_ps = o.inter ? 64 : o.c_ps_b;
+    o.q_step = o.inter ? 128u : 64u;
     return o;
   };
   // one MFMA slot of quadrant (mq, nq), optionally with the epilogue job "store m-tiles J0, J0+1 of tile (tm0, tn0)"
@@ -1597,6 +1738,155 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
 #if GRAM_PP_ABL & 8
   const unsigned long long abl_t0 = __builtin_amdgcn_s_memtime(), abl_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  if constexpr (INSL) {
+    const float *rs_cur = nullptr, *rs_prev = nullptr;
+    auto set_tile = [&]() {
+      int mt, nr;
+      decode(tile, mt, nr);
+      m0 = mt * TB;
+      n0 = nt_of(nr) * TB;
+      rs_cur = reinterpret_cast<const float*>(smem + RS_OFF) + tpar * 256 + wr * 128;  // (all 1.0 when the GEMM has no row scales)
+      rs_prev = reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128;
+    };
+    // two-piece 16-bit outputs: the passes of the in-load-slot epilogue (schedule above) around the same eight phases.  The k-tile
+    // pairs of a tile come in three compile-time flavours -- the first one behind a previous tile (MODE 1: that tile's last passes),
+    // plain ones (MODE 0: exactly the loop of the other kernels, no epilogue code or branches in it), the last one (MODE 2: this
+    // tile's first passes) -- so the steady state is not touched.  nkt >= 4: the first and the last pair are different pairs.
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    const std::false_type NT{};
+    char* const PT = patch;
+    auto pair_body = [&](auto MODEc, bool first) {
+      constexpr int MODE = decltype(MODEc)::value;
+      // exact store counts: all 128 rows of the wave exist in the tile being stored (its output addressing is rebuilt in every slot
+      // that stores -- a handful of scalar operations -- rather than kept live across the pair)
+      const bool full = MODE == 1 ? M - (pm0 + wr * 128) >= 128 : MODE == 2 ? M - (m0 + wr * 128) >= 128 : false;
+      // ================= even k-tile (buffers 0): quadrants 00, 01, 11, 10
+      if constexpr (MODE == 1) {
+        issue(1, 0);  // W_n0(kk+2)
+        const PPOut o = make_out(pm0, pn0);
+        passes(o, rs_prev, PT, std::integral_constant<int, 3>{}, std::integral_constant<int, 12>{}, std::integral_constant<int, 8>{});
+        zero_q(0, 0);
+        read_a(0, 0);
+        end_load_slot_st(full, std::integral_constant<int, 20>{});
+      } else {
+        read_a(0, 0);
+        issue(1, 0);
+        end_load_slot(0);
+      }
+      mma(0, 0, NT);
+      if constexpr (MODE == 1) {
+        issue(0, 0);  // A_m0(kk+2)
+        const PPOut o = make_out(pm0, pn0);
+        passes(o, rs_prev, PT, std::integral_constant<int, 13>{}, std::integral_constant<int, 14>{}, std::integral_constant<int, 9>{});
+        read_w(0, 1);
+        end_load_slot_st(full, std::integral_constant<int, 26>{});
+      } else {
+        read_w(0, 1);
+        issue(0, 0);
+        end_load_slot(0);
+      }
+      mma(0, 1, NT);
+      if (first && has_rs && wave < 4) {  // this tile's 256 row scales -> LDS by DMA (64 rows per wave); first read in the tile's last pair
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        dma4_asm(lds0 + RS_OFF + tpar * 1024 + wave * 256, (uint32_t)min(m0 + wave * 64 + ln, M - 1) * 4u,
+                 reinterpret_cast<const char*>(ep.ss_in));
+      }
+      if constexpr (MODE == 1) {
+        issue(2, 0);  // W_n1(kk+2)
+        const PPOut o = make_out(pm0, pn0);
+        passes(o, rs_prev, PT, std::integral_constant<int, 15>{}, std::integral_constant<int, 10>{}, std::integral_constant<int, -1>{});
+        zero_q(1, 1);
+        read_a(0, 1);
+        end_load_slot_st(full, std::integral_constant<int, 30>{});
+      } else {
+        read_a(0, 1);
+        issue(2, 0);
+        end_load_slot(0);
+      }
+      mma(1, 1, NT);
+      if constexpr (MODE == 1) {
+        issue(3, 0);  // A_m1(kk+2)
+        const PPOut o = make_out(pm0, pn0);
+        passes(o, rs_prev, PT, std::integral_constant<int, 11>{}, std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
+        zero_q(1, 0);
+        read_w(1, 1);  // W_n1 of the odd k-tile that follows
+        end_load_slot_st(full, std::integral_constant<int, 26>{});
+      } else {
+        read_w(1, 1);
+        issue(3, 0);
+        end_load_slot(0);
+      }
+      mma(1, 0, NT);
+      advance();
+      // ================= odd k-tile (buffers 1): quadrants 01, 00, 10, 11
+      read_a(1, 0);
+      issue(2, 1);  // W_n1(kk+3)
+      if constexpr (MODE == 1) end_load_slot_st(full, std::integral_constant<int, 22>{});
+      else end_load_slot(0);
+      mma(0, 1, NT);
+      if constexpr (MODE == 2) {  // this tile's quadrant 01 is final
+        issue(0, 1);  // A_m0(kk+3)
+        const PPOut o = make_out(m0, n0);
+        passes(o, rs_cur, PT, std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, -1>{});
+        read_w(1, 0);
+        end_load_slot_st(full, std::integral_constant<int, 4>{});
+      } else {
+        read_w(1, 0);
+        issue(0, 1);
+        if constexpr (MODE == 1) end_load_slot_st(full, std::integral_constant<int, 16>{});
+        else end_load_slot(0);
+      }
+      mma(0, 0, NT);
+      if constexpr (MODE == 2) {  // ... and 00
+        issue(1, 1);  // W_n0(kk+3)
+        const PPOut o = make_out(m0, n0);
+        passes(o, rs_cur, PT, std::integral_constant<int, 6>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, -1>{});
+        read_a(1, 1);
+        end_load_slot_st(full, std::integral_constant<int, 8>{});
+      } else {
+        read_a(1, 1);
+        issue(1, 1);
+        if constexpr (MODE == 1) end_load_slot_st(full, std::integral_constant<int, 10>{});
+        else end_load_slot(0);
+      }
+      mma(1, 0, NT);
+      if constexpr (MODE == 2) {
+        issue(3, 1);  // A_m1(kk+3)
+        const PPOut o = make_out(m0, n0);
+        passes(o, rs_cur, PT, std::integral_constant<int, 7>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+        zero_q(0, 1);
+        read_w(0, 0);  // W_n0 of the even k-tile that follows
+        end_load_slot_st(full, std::integral_constant<int, 14>{});
+      } else {
+        read_w(0, 0);
+        issue(3, 1);
+        if constexpr (MODE == 1) end_load_slot_st(full, std::integral_constant<int, 4>{});
+        else end_load_slot(0);
+      }
+      mma(1, 1, NT);
+      advance();
+    };
+    // The tile loop is rotated -- [plain pairs | last pair | next tile's first pair] -- so that no two flavours of a pair meet at a
+    // join (a join of two 190-register states makes hipcc copy and spill them).
+    set_tile();
+    pair_body(I0{}, true);
+    while (true) {
+      for (int kt = 2; kt + 2 < nkt; kt += 2) pair_body(I0{}, false);
+      pair_body(I2{}, false);
+      const bool more = tile + G < ntiles;
+      pending = true;
+      pm0 = m0;
+      pn0 = n0;
+      tpar ^= 1;
+      if (!more) break;
+      tile += G;
+      set_tile();
+      pair_body(I1{}, true);
+    }
+  } else {
   while (true) {
     {
       int mt, nr;
@@ -1607,6 +1897,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     }
     const float* rs_cur = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + tpar * 256 + wr * 128 : nullptr;
     const float* rs_prev = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128 : nullptr;
+    {
     for (int kt = 0; kt < nkt; kt += 2) {
       const bool first = kt == 0, last = kt + 2 >= nkt;
       // bf16 epilogues of FULL tiles issue exactly 4 stores per store slot (the slots p2, p3 of a tile's last k-tile
@@ -1663,6 +1954,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       run_slot(1, 1, !TEND && st_cur, std::integral_constant<int, 2>{}, m0, n0, rs_cur);
       if (last && !TEND) zero_half(0);
       advance();
+    }
     }
     const bool more = tile + G < ntiles;
     if constexpr (TEND) {
@@ -1775,6 +2067,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     if (!more) break;
     tile += G;
   }
+  }
 #if GRAM_PP_ABL & 8
   if (tid == 0 && blockIdx.x < 1024) {
     g_pp_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - abl_t0;
@@ -1788,7 +2081,14 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   pp_barrier();
-  if constexpr (!TEND) {  // (TEND: stored at the end of every tile)
+  if constexpr (INSL) {  // what the in-load-slot epilogue of a next tile would have stored: 00's last m-tile, quadrants 11 and 10
+    const float* rs_prev = reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128;
+    const PPOut o = make_out(pm0, pn0);
+    char* const PT = smem + wave * 6144;  // (the half-tile buffers are dead: private patches)
+    passes(o, rs_prev, PT, std::integral_constant<int, 3>{}, std::integral_constant<int, 12>{}, std::integral_constant<int, 13>{});
+    passes(o, rs_prev, PT, std::integral_constant<int, 14>{}, std::integral_constant<int, 15>{}, std::integral_constant<int, 8>{});
+    passes(o, rs_prev, PT, std::integral_constant<int, 9>{}, std::integral_constant<int, 10>{}, std::integral_constant<int, 11>{});
+  } else if constexpr (!TEND) {  // (TEND: stored at the end of every tile)
     const float* rs_prev = has_rs ? reinterpret_cast<const float*>(smem + RS_OFF) + (tpar ^ 1) * 256 + wr * 128 : nullptr;
     if constexpr (KV) {
 #pragma unroll
