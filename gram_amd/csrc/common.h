@@ -69,6 +69,44 @@ __device__ __forceinline__ bf16x8 zero_bf16x8() {
   return z;
 }
 
+// v -> its two 16-bit pieces hi = r16(v), lo = r16(v - hi), two values per call, each piece packed into one dword.  IEEE-half build:
+// v_cvt_pk_f16_f32 for the pairs and v_fma_mix_f32 (f16 source x -1 + f32) for the remainders: 4 vector instructions per pair where the
+// plain C++ (convert, convert back, subtract, convert, pack) compiles to 6-7 -- the tile-end epilogues of the two-piece GEMMs and the
+// encoder attention's softmax are bound by their vector-instruction count.  v - hi is exact in fp32 either way (hi is within half a
+// 16-bit ulp of v), so the pieces are the same bits as the plain form's.
+__device__ __forceinline__ void split2_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+#ifdef GRAM_F16
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef _Float16 h16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ ab = {a, b};
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(ab, h16x2_));
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+  const f32x2_ r = {ra, rb};
+  lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, h16x2_));
+#else
+  typedef bf16 b16x2_ __attribute__((ext_vector_type(2)));
+  b16x2_ h = {(bf16)a, (bf16)b};
+  b16x2_ l = {(bf16)(a - (float)h[0]), (bf16)(b - (float)h[1])};
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+#endif
+}
+__device__ __forceinline__ void split2x4(f32x4 v, uint2& hi, uint2& lo) {
+  split2_pair(v[0], v[1], hi.x, lo.x);
+  split2_pair(v[2], v[3], hi.y, lo.y);
+}
+
+// Sum of squares of four values (a partial of the folded T5LayerNorm) in ONE spelled-out arithmetic: every GEMM kernel that produces
+// these partials must round the same way (a user's result does not depend on which kernel its batch size selects), and hipcc decides
+// per call site whether a * a + b * b becomes an fma -- a decision that changed when unrelated code next to it did.
+__device__ __forceinline__ float sumsq4(f32x4 v) {
+  const float a = __builtin_fmaf(v[1], v[1], v[0] * v[0]);
+  const float b = __builtin_fmaf(v[3], v[3], v[2] * v[2]);
+  return a + b;
+}
+
 // products of the two-piece mode (gram_hip.h, gram_split_t): (A piece, B piece) pairs, smallest first
 template <int S> struct SplitTab;
 template <> struct SplitTab<1> { static constexpr int NP = 1; static constexpr int A[3] = {0, 0, 0}; static constexpr int B[3] = {0, 0, 0}; };

@@ -28,8 +28,11 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ks = smem;                       // [S][128 * 128]
   char* vts = smem + S * 128 * 128;      // [S][64 * 256]
-  float* bias_s = reinterpret_cast<float*>(smem + S * 2 * 128 * 128);  // [256]
-  float* mask_s = bias_s + 256;                                        // [128]
+  // relative bias of head h by (key - query + 127), as FOUR copies shifted by 0..3 floats: a lane's four consecutive keys of a score
+  // fragment are then one ALIGNED 16-byte read from the copy matching its query's residue, and the fragment's MFMA chain starts from it
+  // (the bias is the accumulator's initial value: no add, 16 ds_read_b128 per lane instead of 64 ds_read_b32)
+  float* bias_s = reinterpret_cast<float*>(smem + S * 2 * 128 * 128);  // [4][256]: bias_s[r][i] = bias[i + r]
+  float* mask_s = bias_s + 4 * 256;                                    // [128]
 
   const int h = blockIdx.x, p = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,9 +60,18 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
       for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(vts + pc * 64 * 256 + vtswz(c * 8 + e, row)) = vv[it][e];
     }
   }
-  if (tid < 255) bias_s[tid] = bias[h * 255 + tid];
-  if (tid < L) mask_s[tid] = mask[(size_t)p * L + tid] ? 0.f : 1.f;
-  __syncthreads();
+  if (tid < 255) {
+    const float bv = bias[h * 255 + tid];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (tid >= r) bias_s[r * 256 + tid - r] = bv;
+  }
+  bool key_masked = false;
+  if (tid < L) {
+    key_masked = mask[(size_t)p * L + tid] == 0;
+    mask_s[tid] = key_masked ? 1.f : 0.f;
+  }
+  const bool any_masked = __syncthreads_or(key_masked) != 0;  // (an all-valid passage skips the mask pass: wave-uniform)
 
   const int q0 = wave * 32;
   if (q0 >= L) return;
@@ -88,7 +100,9 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
       }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // S^T rows of this lane: keys 32 k2 + 8 g + 4 t + 0..3, query q0 + 16 nt + c -> bias index key - query + 127
+        const int idx0 = 32 * k2 + 8 * g + 4 * t + 127 - (q0 + 16 * nt + c), r = idx0 & 3;
+        f32x4 a = *reinterpret_cast<const f32x4*>(bias_s + r * 256 + (idx0 - r));
 #pragma unroll
         for (int pr = 0; pr < T::NP; ++pr) {
           a = mfma16(kf[T::A[pr]][0], qf[T::B[pr]][nt][0], a);
@@ -102,7 +116,6 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
   float mxq[2], l[2] = {0.f, 0.f};
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
-    const int query = q0 + 16 * nt + c;
     float mx = GRAM_FMIN;
 #pragma unroll
     for (int k2 = 0; k2 < NKS; ++k2)
@@ -110,10 +123,11 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int key = 32 * k2 + 8 * g + 4 * t + j;
-          float v = s[k2][t][nt][j] + bias_s[key - query + 127];
-          v = (mask_s[key] != 0.f) ? GRAM_FMIN : v;
-          s[k2][t][nt][j] = v;
+          float v = s[k2][t][nt][j];
+          if (any_masked) {
+            v = (mask_s[32 * k2 + 8 * g + 4 * t + j] != 0.f) ? GRAM_FMIN : v;
+            s[k2][t][nt][j] = v;
+          }
           mx = fmaxf(mx, v);
         }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -121,7 +135,8 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
     mxq[nt] = mx;
   }
 
-  // O^T = V^T P^T, P = exp(S^T - max) formed 32 keys at a time (as bf16 pieces) right before its MFMAs
+  // O^T = V^T P^T, P = exp(S^T - max) formed 32 keys at a time (as 16-bit pieces) right before its MFMAs
+  // (exp(s - m) with the subtraction first: a fully masked row is all finfo.min, and min - min = 0 must give the reference's uniform row)
   f32x4 o[4][2];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
@@ -131,20 +146,31 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
   for (int k2 = 0; k2 < NKS; ++k2) {
     bf16x8 pf[S][2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt) {
+      if constexpr (S == 2) {  // both pieces of a pair of probabilities at once (split2_pair: 4 vector instructions per pair)
+        uint32_t w[2][4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float e = __expf(s[k2][t][nt][j] - mxq[nt]);
-          l[nt] += e;
-#pragma unroll
-          for (int pc = 0; pc < S; ++pc) {
-            const bf16 b = (bf16)e;
-            pf[pc][nt][4 * t + j] = b;
-            e -= (float)b;
+          for (int j = 0; j < 4; j += 2) {
+            const float e0 = __expf(s[k2][t][nt][j] - mxq[nt]), e1 = __expf(s[k2][t][nt][j + 1] - mxq[nt]);
+            l[nt] += e0;
+            l[nt] += e1;
+            split2_pair(e0, e1, w[0][2 * t + (j >> 1)], w[1][2 * t + (j >> 1)]);
           }
-        }
+        pf[0][nt] = __builtin_bit_cast(bf16x8, make_uint4(w[0][0], w[0][1], w[0][2], w[0][3]));
+        pf[1][nt] = __builtin_bit_cast(bf16x8, make_uint4(w[1][0], w[1][1], w[1][2], w[1][3]));
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float e = __expf(s[k2][t][nt][j] - mxq[nt]);
+            l[nt] += e;
+            pf[0][nt][4 * t + j] = (bf16)e;
+          }
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int d = 16 * mt + c;
@@ -168,17 +194,18 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
     bf16* orow = out + ((size_t)p * L + query) * inner * S;  // (S == 2: the O GEMM's interleaved A operand, [rows][2 * inner])
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      f32x4 v = o[mt][nt] * inv_l;
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc) {
+      const f32x4 v = o[mt][nt] * inv_l;
+      const int n = h * 64 + 16 * mt + 4 * g;
+      if constexpr (S == 2) {
+        uint2 hi, lo;
+        split2x4(v, hi, lo);
+        *reinterpret_cast<uint2*>(orow + inter_off(n, 0)) = hi;
+        *reinterpret_cast<uint2*>(orow + inter_off(n, 1)) = lo;
+      } else {
         bf16x4 r;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          r[j] = (bf16)v[j];
-          v[j] -= (float)r[j];
-        }
-        const int n = h * 64 + 16 * mt + 4 * g;
-        *reinterpret_cast<bf16x4*>(orow + (S == 2 ? inter_off(n, pc) : n)) = r;
+        for (int j = 0; j < 4; ++j) r[j] = (bf16)v[j];
+        *reinterpret_cast<bf16x4*>(orow + n) = r;
       }
     }
   }
@@ -188,7 +215,7 @@ template <int S>
 int launch_enc(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H, long qkv_pstride,
                hipStream_t st) {
   const dim3 grid(H, P), block(256);
-  constexpr int smem = S * 2 * 128 * 128 + (256 + 128) * 4;
+  constexpr int smem = S * 2 * 128 * 128 + (4 * 256 + 128) * 4;
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(enc_attn_kernel<1, S>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -318,7 +318,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
               *reinterpret_cast<uint2*>(xrow + (ep.split == 2 ? inter_off(n, pc) : n)) = pk;
               rem -= unpack_bf16x4(pk);
             }
-            ssq[i / 4] += (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
+            ssq[i / 4] += sumsq4(nv);
           }
         } else if constexpr (EPI == GRAM_EPI_F32) {
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n) = v;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
               *reinterpret_cast<uint2*>(xrow + (ep.split == 2 ? inter_off(n, pc) : n)) = pk;
               rem -= unpack_bf16x4(pk);
             }
-            ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
+            ssq = sumsq4(val);
           }
         }
       }
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
           *reinterpret_cast<uint2*>(xrow + (ep.split == 2 ? inter_off(n, p) : n)) = pk;
           rem -= unpack_bf16x4(pk);
         }
-        ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
+        ssq = sumsq4(val);
       }
     }
     if (ep.ss_out) {  // (wave-uniform) the first two butterfly steps of the 64-column epilogues: the 4 lanes of a row in this n-tile
@@ -984,13 +984,19 @@ __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, c
           for (int e = 0; e < 4; ++e) v[i][e] = fmaxf(v[i][e], 0.f);
         }
       }
+      uint2 pcs[2][4];  // the values' pieces (both at once in the two-piece mode: split2x4)
+      if (o.split == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split2x4(v[i], pcs[0][i], pcs[1][i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pcs[0][i] = pcs[1][i] = pack_bf16x4(v[i]);
+      }
       for (int pc = 0; pc < o.split; ++pc) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int chunk = (i * 2 + (g >> 1)) ^ (r16 & 7);
-          const uint2 pk = pack_bf16x4(v[i]);
-          *reinterpret_cast<uint2*>(patch + r16 * 128 + chunk * 16 + (g & 1) * 8) = pk;
-          v[i] -= unpack_bf16x4(pk);
+          *reinterpret_cast<uint2*>(patch + r16 * 128 + chunk * 16 + (g & 1) * 8) = pc == 0 ? pcs[0][i] : pcs[1][i];
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1026,7 +1032,7 @@ __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, c
           if constexpr (EPI == GRAM_EPI_F32_ADD) {
             if (o.xb) {
               *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + c * 8)) = pack_bf16x4(val);
-              ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
+              ssq = sumsq4(val);
             }
           }
         }
@@ -1096,8 +1102,8 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
                 // piece 1's): lanes c and c ^ 1 swap one piece each, so that the even lane stores 16 B of piece 0 (columns 4c .. 4c + 7)
                 // and the odd lane 16 B of piece 1 -- one 16-B store per lane instead of two 8-B ones (the tile-end store tail is bound by
                 // its instruction count: an 8-B-per-lane store costs as much as a 16-B one)
-                const uint2 p0 = pack_bf16x4(val);
-                const uint2 p1 = pack_bf16x4(val - unpack_bf16x4(p0));
+                uint2 p0, p1;
+                split2x4(val, p0, p1);
                 const bool odd = c & 1;
                 const uint2 send = odd ? p0 : p1;
                 uint2 recv;
@@ -1109,7 +1115,7 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
               } else {
                 *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + (uint32_t)(c * 8))) = pack_bf16x4(val);
               }
-              ssq = (val[0] * val[0] + val[1] * val[1]) + (val[2] * val[2] + val[3] * val[3]);
+              ssq = sumsq4(val);
             }
           }
         }
@@ -1596,8 +1602,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
             v1[e] = fmaxf(v1[e], 0.f);
           }
         }
-        const uint2 h0 = pack_bf16x4(v0), h1 = pack_bf16x4(v1);
-        const uint2 l0 = pack_bf16x4(v0 - unpack_bf16x4(h0)), l1 = pack_bf16x4(v1 - unpack_bf16x4(h1));
+        uint2 h0, h1, l0, l1;
+        split2x4(v0, h0, l0);
+        split2x4(v1, h1, l1);
         *reinterpret_cast<uint2*>(wb + u * 2048 + (((0 + gh) ^ sw) << 4)) = h0;
         *reinterpret_cast<uint2*>(wb + u * 2048 + (((2 + gh) ^ sw) << 4)) = h1;
         *reinterpret_cast<uint2*>(wb + u * 2048 + (((4 + gh) ^ sw) << 4)) = l0;
@@ -2026,9 +2033,16 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
                 for (int pcs = 0; pcs < 8; ++pcs) {
                   const int jj = pcs >> 2, pi = pcs & 3;
                   f32x4& v = acc[pi][J0 + jj];
-                  const uint2 pk = pack_bf16x4(v);
+                  uint2 pk;
+                  if (pc == 0) {  // both pieces at once (split2x4); the low one waits in the accumulator's first two registers
+                    uint2 lo;
+                    split2x4(v, pk, lo);
+                    v[0] = __uint_as_float(lo.x);
+                    v[1] = __uint_as_float(lo.y);
+                  } else {
+                    pk = make_uint2(__float_as_uint(v[0]), __float_as_uint(v[1]));
+                  }
                   *reinterpret_cast<uint2*>(wbase + pi * 1024 + (((jj * 2 + (lg >> 1)) ^ wsw) * 16)) = pk;
-                  v -= unpack_bf16x4(pk);
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
