@@ -2186,12 +2186,16 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
 //   M >= 32768 (encoder, bank):  ping-pong 256x256 persistent kernel 1 100-1 190 > 256x128 tiles 780-815 > 128x128
 //   lm_head with logits stored (N = 32128, not a multiple of 256):  256x128 783 > 128x128 614
 //   M ~ 10240 (decoder):         128x128 475-832 > 256x128 418-801 > persistent 299-696 (too few tiles per CU)
+int pp_min_m() {  // rows from which the persistent ping-pong kernel is considered (GRAM_GEMM_PP_MINM: A/B hook)
+  static const int v = getenv("GRAM_GEMM_PP_MINM") ? atoi(getenv("GRAM_GEMM_PP_MINM")) : 32768;
+  return v;
+}
 int pick_variant(int M, int N, int K) {
   if (g_force_variant >= 0) return g_force_variant;
   const long tiles256 = (long)((M + 255) / 256) * (N / BN);
   // persistent 256x256: needs >= ~2 tiles per CU to amortise its fill/drain; with a long K (FFN-wo, K = 4*d) it
   // already wins at 480 tiles (M = 40960, N = 768: 230 us vs 277 us for the 128x128 variant)
-  if (N % 256 == 0 && M >= 32768 && (tiles256 >= 2048 || K >= 2048)) return V_PP;
+  if (N % 256 == 0 && M >= pp_min_m() && (tiles256 >= 2048 * (long)pp_min_m() / 32768 || K >= 2048)) return V_PP;
   if (tiles256 >= 2048) return V_DMA_M256;
   // at most one workgroup per CU: nothing else is resident to hide a DMA's latency -> the deep-ring instantiations (64- or 128-row tiles)
   static const int use_ring = getenv("GRAM_GEMM_RING") ? atoi(getenv("GRAM_GEMM_RING")) : 1;  // A/B hook
@@ -2250,7 +2254,7 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
   // (two-piece operands: the ping-pong kernel's X3 instantiation; its results leave at the tile end)
   auto pp = [&]() { return launch_pp<EPI, X3>(A, W, M, N, K, lda, ep, st); };
   if constexpr (EPI == GRAM_EPI_F32_LSE) {  // 64-column wave tiles only: the ping-pong kernel (partials only) or the 128-row kernels
-    if ((g_force_variant == V_PP || (g_force_variant < 0 && pp_ok && M >= 32768)) && !ep.C) {
+    if ((g_force_variant == V_PP || (g_force_variant < 0 && pp_ok && M >= pp_min_m())) && !ep.C) {
       const int r = pp();
       if (r != GRAM_E_ARG) return r;
     }
@@ -2262,7 +2266,7 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
                            : launch_dma<EPI, 4, 1, X3>(A, W, M, N, K, lda, ep, st);
   } else {
   if constexpr (EPI == GRAM_EPI_F32_ADD) {  // big-M residual GEMMs: the ping-pong kernel with its tile-end epilogue, whatever N and K
-    if (g_force_variant < 0 && pp_ok && M >= 32768) {
+    if (g_force_variant < 0 && pp_ok && M >= pp_min_m()) {
       const int r = pp();
       if (r != GRAM_E_ARG) return r;
     }
