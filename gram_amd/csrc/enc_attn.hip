@@ -14,6 +14,13 @@
 #include "common.h"
 #include "prof.h"
 
+// Ablation builds (`make EABL=n` -> libgram_hip_eabl<n>.so, tests/bench_enc_attn.py; results wrong; the product library has none of it).
+// Bits: 1 no QK^T MFMAs, 2 no exp / piece split (P = a constant), 4 no PV MFMAs, 8 no global K/V loads, 16 no V^T scatter into LDS,
+// 32 no output stores, 64 no query loads.
+#ifndef GRAM_ENC_ABL
+#define GRAM_ENC_ABL 0
+#endif
+
 namespace {
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -49,15 +56,25 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
     for (int it = 0; it < NKS; ++it) {
       const int i = tid + it * 256, row = i >> 3, c = i & 7;
       const bf16* src = base + pc * qkv_pstride + (size_t)row * rs + c * 8;
-      kv[it] = ld_stream_b128(src + inner);
-      vv[it] = ld_stream_b128(src + 2 * inner);
+      if constexpr ((GRAM_ENC_ABL & 8) != 0) {
+        kv[it] = zero_bf16x8();
+        vv[it] = zero_bf16x8();
+        asm volatile("" : "+v"(kv[it]), "+v"(vv[it]));
+      } else {
+        kv[it] = ld_stream_b128(src + inner);
+        vv[it] = ld_stream_b128(src + 2 * inner);
+      }
     }
 #pragma unroll
     for (int it = 0; it < NKS; ++it) {
       const int i = tid + it * 256, row = i >> 3, c = i & 7;
       *reinterpret_cast<bf16x8*>(ks + pc * 128 * 128 + kswz(row, c)) = kv[it];
+      if constexpr ((GRAM_ENC_ABL & 16) != 0) {
+        *reinterpret_cast<bf16x8*>(vts + pc * 64 * 256 + kswz(row, c)) = vv[it];  // (same bytes, one 16-B store, wrong layout)
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(vts + pc * 64 * 256 + vtswz(c * 8 + e, row)) = vv[it][e];
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(vts + pc * 64 * 256 + vtswz(c * 8 + e, row)) = vv[it][e];
+      }
     }
   }
   if (tid < 255) {
@@ -84,7 +101,12 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int kd = 0; kd < 2; ++kd)
-        qf[pc][nt][kd] = ld_stream_b128(base + pc * qkv_pstride + (size_t)(q0 + 16 * nt + c) * rs + 32 * kd + 8 * g);
+        if constexpr ((GRAM_ENC_ABL & 64) != 0) {
+          qf[pc][nt][kd] = zero_bf16x8();
+          asm volatile("" : "+v"(qf[pc][nt][kd]));
+        } else {
+          qf[pc][nt][kd] = ld_stream_b128(base + pc * qkv_pstride + (size_t)(q0 + 16 * nt + c) * rs + 32 * kd + 8 * g);
+        }
 
   f32x4 s[NKS][2][2];
 #pragma unroll
@@ -103,10 +125,14 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
         // S^T rows of this lane: keys 32 k2 + 8 g + 4 t + 0..3, query q0 + 16 nt + c -> bias index key - query + 127
         const int idx0 = 32 * k2 + 8 * g + 4 * t + 127 - (q0 + 16 * nt + c), r = idx0 & 3;
         f32x4 a = *reinterpret_cast<const f32x4*>(bias_s + r * 256 + (idx0 - r));
+        if constexpr ((GRAM_ENC_ABL & 1) != 0) {
+          a[0] += (float)kf[0][0][0] + (float)qf[0][nt][0][0];  // (keep the operands live)
+        } else {
 #pragma unroll
-        for (int pr = 0; pr < T::NP; ++pr) {
-          a = mfma16(kf[T::A[pr]][0], qf[T::B[pr]][nt][0], a);
-          a = mfma16(kf[T::A[pr]][1], qf[T::B[pr]][nt][1], a);
+          for (int pr = 0; pr < T::NP; ++pr) {
+            a = mfma16(kf[T::A[pr]][0], qf[T::B[pr]][nt][0], a);
+            a = mfma16(kf[T::A[pr]][1], qf[T::B[pr]][nt][1], a);
+          }
         }
         s[k2][t][nt] = a;
       }
@@ -147,7 +173,17 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
     bf16x8 pf[S][2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      if constexpr (S == 2) {  // both pieces of a pair of probabilities at once (split2_pair: 4 vector instructions per pair)
+      if constexpr ((GRAM_ENC_ABL & 2) != 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) t += s[k2][tt][nt][j];
+        l[nt] += t;
+        const uint32_t wv = __float_as_uint(t) & 0x3c003c00u;
+        pf[0][nt] = __builtin_bit_cast(bf16x8, make_uint4(wv, wv, wv, wv));
+        if constexpr (S == 2) pf[S - 1][nt] = pf[0][nt];
+      } else if constexpr (S == 2) {  // both pieces of a pair of probabilities at once (split2_pair: 4 vector instructions per pair)
         uint32_t w[2][4];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -180,7 +216,10 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int pr = 0; pr < T::NP; ++pr) o[mt][nt] = mfma16(vf[T::A[pr]], pf[T::B[pr]][nt], o[mt][nt]);
+        for (int pr = 0; pr < T::NP; ++pr) {
+          if constexpr ((GRAM_ENC_ABL & 4) != 0) o[mt][nt][0] += (float)vf[T::A[pr]][0] + (float)pf[T::B[pr]][nt][0];
+          else o[mt][nt] = mfma16(vf[T::A[pr]], pf[T::B[pr]][nt], o[mt][nt]);
+        }
     }
   }
 
@@ -199,8 +238,10 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
       if constexpr (S == 2) {
         uint2 hi, lo;
         split2x4(v, hi, lo);
-        *reinterpret_cast<uint2*>(orow + inter_off(n, 0)) = hi;
-        *reinterpret_cast<uint2*>(orow + inter_off(n, 1)) = lo;
+        if (!(GRAM_ENC_ABL & 32) || hi.x == 0x12345678u) {
+          *reinterpret_cast<uint2*>(orow + inter_off(n, 0)) = hi;
+          *reinterpret_cast<uint2*>(orow + inter_off(n, 1)) = lo;
+        }
       } else {
         bf16x4 r;
 #pragma unroll
