@@ -2195,7 +2195,10 @@ int pick_variant(int M, int N, int K) {
   const long tiles256 = (long)((M + 255) / 256) * (N / BN);
   // persistent 256x256: needs >= ~2 tiles per CU to amortise its fill/drain; with a long K (FFN-wo, K = 4*d) it
   // already wins at 480 tiles (M = 40960, N = 768: 230 us vs 277 us for the 128x128 variant)
-  if (N % 256 == 0 && M >= pp_min_m() && (tiles256 >= 2048 * (long)pp_min_m() / 32768 || K >= 2048)) return V_PP;
+  // (1 536 tiles of 256 x 128 = 3 ping-pong tiles per CU; measured on the decoder's cross-q GEMM, M = 81 920, N = 768: 1 110 -> ~1 250
+  // TFLOP/s executed, GEMM time per step 1 032.7 -> 1 027.5 ms: profiles/r03s_pp_mintiles_ab.txt)
+  static const long pp_min_tiles = getenv("GRAM_GEMM_PP_MINTILES") ? atol(getenv("GRAM_GEMM_PP_MINTILES")) : 1536;  // A/B hook
+  if (N % 256 == 0 && M >= pp_min_m() && (tiles256 >= pp_min_tiles * (long)pp_min_m() / 32768 || K >= 2048)) return V_PP;
   if (tiles256 >= 2048) return V_DMA_M256;
   // at most one workgroup per CU: nothing else is resident to hide a DMA's latency -> the deep-ring instantiations (64- or 128-row tiles)
   static const int use_ring = getenv("GRAM_GEMM_RING") ? atoi(getenv("GRAM_GEMM_RING")) : 1;  // A/B hook
