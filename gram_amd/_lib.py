@@ -17,7 +17,7 @@ GRAM_MAX_DEC_LEN = 32
 GRAM_MAX_PASSAGE_LEN = 128
 EPI_BF16, EPI_BF16_RELU, EPI_F32_ADD, EPI_F32, EPI_KV_BANK = range(5)
 K_GEMM, K_ENC_ATTN, K_CROSS_ATTN, K_DEC_SELF_ATTN, K_ROWOPS, K_LSE, K_BEAM = range(7)
-E_ARG, E_WORKSPACE, E_BEAM = -1, -2, -3
+E_ARG, E_WORKSPACE, E_BEAM, E_NONFINITE = -1, -2, -3, -4
 ABI_VERSION = 5
 # two-piece mode (gram_hip.h, gram_split_t): 16-bit pieces per value -> MFMA products per product
 MAX_PIECES = 2
@@ -202,5 +202,7 @@ def check(code: int, what: str) -> None:
     if code == 0:
         return
     names = {E_ARG: "GRAM_E_ARG (bad shape / unsupported size)", E_WORKSPACE: "GRAM_E_WORKSPACE",
-             E_BEAM: "GRAM_E_BEAM (impossible beam state; HF would raise here)"}
+             E_BEAM: "GRAM_E_BEAM (impossible beam state; HF would raise here)",
+             E_NONFINITE: "GRAM_E_NONFINITE (a returned score is NaN / +inf: an activation left the range of the 16-bit pieces -- IEEE half, "
+                          "|x| <= 65504; build and load the bfloat16 library: make -C gram_amd/csrc PIECE=bf16, GRAM_LIB=.../libgram_hip_bf16.so)"}
     raise GramHipError(f"{what} failed: {names.get(code, f'hipError {code}')}")

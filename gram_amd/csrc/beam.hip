@@ -560,6 +560,8 @@ __global__ void beam_finalize_kernel(gram_beam_state_t st, int nret, int max_len
     for (int p = 0; p < len && p < max_length; ++p) dst[p] = ht[(size_t)best * T + p];
     if (len < max_length) dst[len] = st.eos;
     scores[b * nret + j] = (float)hs[best];
+    // log-probabilities are <= 0: a NaN or +inf score means an activation overflowed the 16-bit pieces somewhere upstream (GRAM_E_NONFINITE)
+    if (hs[best] != hs[best] || hs[best] > 1.0e30) st.error[0] = 4;
     maxlen = len > maxlen ? len : maxlen;
   }
   int w = maxlen + 1;

@@ -706,6 +706,7 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     *width_host = host[0];
+    if (host[1] == 4) return GRAM_E_NONFINITE;
     if (host[1] != 0) return GRAM_E_BEAM;
   }
   return 0;

@@ -30,6 +30,8 @@ extern "C" {
 #define GRAM_E_ARG (-1)       /* bad shape / unsupported size                           */
 #define GRAM_E_WORKSPACE (-2) /* workspace too small (see gram_workspace_bytes)          */
 #define GRAM_E_BEAM (-3)      /* device beam bookkeeping flagged an impossible state      */
+#define GRAM_E_NONFINITE (-4) /* a returned score is NaN or +inf: an activation left the range of the 16-bit pieces (IEEE half:
+                                 |x| <= 65 504) -- use the bfloat16 build (make PIECE=bf16)             */
 
 #define GRAM_MAX_BEAMS 64      /* K <= 64 (reference default 50, headline 20)             */
 #define GRAM_MAX_DEC_LEN 32    /* max_length <= 32 (reference: 8..12)                     */

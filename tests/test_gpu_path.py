@@ -236,6 +236,30 @@ def test_generate_vs_oracle(gpu, name, B, N, L, K, n_items, depth):
     _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=SCORE_TOL)
 
 
+def test_activation_overflow_of_the_half_pieces_is_an_error(gpu):
+    """IEEE-half pieces hold |x| <= 65 504.  A model whose residual stream leaves that range must not return
+    garbage rankings: generate() raises (GRAM_E_NONFINITE) and names the bfloat16 build as the way out."""
+    from gram_amd import _lib
+    from gram_amd.utils import generation_trie as gt
+    if _lib.piece_dtype() != torch.float16:
+        pytest.skip("bfloat16 build: the pieces have fp32's exponent range")
+    oc, gc = _cfgs("tiny")
+    sd = O.init_state_dict(oc, 3)
+    big = sd["shared.weight"] * 1.0e7  # embeddings (the residual stream's first value) far outside the half range
+    for k in ("shared.weight", "encoder.encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight"):  # (one tied table)
+        sd[k] = big
+    m = gpu.create_model("gram", gc)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    ids, mask = _inputs(g, 2, 2, 32, min(oc.vocab_size, 32100), ragged=False)
+    cands = _random_items(g, 30, 3, 3, 60)
+    fn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
+    with pytest.raises(_lib.GramHipError, match="GRAM_E_NONFINITE"):
+        m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max(len(c) for c in cands), prefix_allowed_tokens_fn=fn,
+                   num_beams=4, num_return_sequences=4, length_penalty=1.0)
+
+
 def test_generate_matches_reference_golden(gpu, golden_dir):
     """Whole path vs the golden produced by reference forward + reference Trie + HF beam search."""
     from gram_amd.utils import generation_trie as gt
