@@ -14,6 +14,8 @@
 //   input_ids gather / _reorder_cache-> sequences and the self-attention ancestor table are
 //                                       advanced in place; K/V caches are never moved
 // One workgroup per user; users are independent, so this shards trivially.
+#include <stdlib.h>
+
 #include "common.h"
 #include "prof.h"
 
@@ -105,7 +107,10 @@ __global__ void beam_init_kernel(gram_beam_state_t st, gram_trie_t tr, int start
   st.node[r] = e < 0 ? -1 : tr.child_node[e];
 }
 
-__global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gram_trie_t tr, const float* __restrict__ logits,
+// NTHR threads per workgroup (= per user): 256 for batches that fill the chip with workgroups; 1 024 for small batches, where one user's
+// sparse logits (a trip computes NTHR / 4 candidates' dot products, each on its 8 lanes) and sort stages are the step's latency
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, gram_trie_t tr, const float* __restrict__ logits,
                                                         const float* __restrict__ lse, int V, int cur_len, int nc_max, int rows_per_user,
                                                         const bf16* __restrict__ hd, const bf16* __restrict__ emb, int d,
                                                         const int32_t* __restrict__ rowpos, int pieces,
@@ -164,14 +169,14 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
     // SPARSE mode: the lm_head GEMM stored only the softmax partials (lse); the logits of the <= K*fan-out
     // allowed tokens are recomputed here as h[row] . E[tok] (bf16 operands, fp32 accumulate; 8 lanes per
     // candidate, 16-byte loads).  The [rows][V] logits tensor (5 GB per step at B = 2048) is never written.
-    for (int ci = C + tid; ci < NC; ci += 256) keys[ci] = 0ull;
+    for (int ci = C + tid; ci < NC; ci += NTHR) keys[ci] = 0ull;
     const int sub = tid & 7, grp = tid >> 3;
     const bool shared0 = rows_per_user == 1;  // step 0: all K beams sit on the same node and the same row
     const int nuniq = shared0 ? s_pre[1] : C;
     const int per = d >> 3;                   // elements per lane
     // (beam, token) of every candidate first, all threads at once, parked in the candidate's key slot: the dot products below then
     // start from LDS instead of a node -> edge -> token chain of global loads per batch
-    for (int ci = tid; ci < nuniq; ci += 256) {
+    for (int ci = tid; ci < nuniq; ci += NTHR) {
       int k = 0;
       if (!shared0)
         while (s_pre[k + 1] <= ci) ++k;
@@ -254,13 +259,14 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
       acc += __shfl_xor(acc, 4, 64);
       return acc;
     };
-    // two candidates per 8-lane group and trip (64 per workgroup): their loads are independent and overlap
-    for (int base = 0; base < nuniq; base += 64) {
+    // two candidates per 8-lane group and trip (NTHR / 4 per workgroup): their loads are independent and overlap
+    constexpr int NG = NTHR / 8;
+    for (int base = 0; base < nuniq; base += 2 * NG) {
       int ci2[2], k2[2], tok2[2], lr2[2];
       bool act2[2];
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
-        ci2[w] = base + 32 * w + grp;
+        ci2[w] = base + NG * w + grp;
         act2[w] = ci2[w] < nuniq;
         const unsigned long long kt = act2[w] ? keys[ci2[w]] : 0ull;
         k2[w] = (int)(kt >> 32);
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
       __syncthreads();
       const int cnt0 = s_pre[1];
       const int off0 = cnt0 > 0 ? tr.child_off[st.node[row0]] : 0;
-      for (int ci = tid; ci < C; ci += 256) {
+      for (int ci = tid; ci < C; ci += NTHR) {
         const int k = ci / cnt0, j = ci - k * cnt0;
         const int tok = tr.child_tok[off0 + j];
         const float sc = (s_log[j] - lse[b]) + st.beam_scores[row0 + k];
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
   }
   if (!isdone && logits != nullptr) {
     // gather: log_softmax at the allowed tokens + running beam score
-    for (int ci = tid; ci < NC; ci += 256) {
+    for (int ci = tid; ci < NC; ci += NTHR) {
       unsigned long long key = 0ull;
       if (ci < C) {
         int k = 0;
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
     while (P < 2 * K) P <<= 1;
     const int top = NC < P ? NC : P;
     auto stage = [&](int n, int kk, int j) {
-      for (int i = tid; i < n; i += 256) {
+      for (int i = tid; i < n; i += NTHR) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const unsigned long long a = keys[i], c = keys[ixj];
@@ -343,10 +349,11 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
     for (int n = NC; n > P; n >>= 1) {
       // blocks (2q, 2q+1) -> block q of the half-size array; every thread reads its pairs before anyone writes
       const int half = n >> 1;
-      unsigned long long mx[32];  // half / 256 <= 8192 / 256 (K * max_fanout <= 16 384); statically indexed: stays in registers
+      constexpr int NMX = 8192 / NTHR;  // half / NTHR <= 8192 / NTHR (K * max_fanout <= 16 384); statically indexed: stays in registers
+      unsigned long long mx[NMX];
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const int o = tid + c * 256;
+      for (int c = 0; c < NMX; ++c) {
+        const int o = tid + c * NTHR;
         if (o < half) {
           const int q = o / P, i = o - q * P;
           const unsigned long long a = keys[(2 * q) * P + i], b2 = keys[(2 * q + 1) * P + i];
@@ -355,8 +362,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
       }
       __syncthreads();
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const int o = tid + c * 256;
+      for (int c = 0; c < NMX; ++c) {
+        const int o = tid + c * NTHR;
         if (o < half) keys[o] = mx[c];
       }
       __syncthreads();
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
   // the Trie edge of every ranked candidate, looked up by 2K threads at once (one binary search each; the walk below ran them one
   // after the other: up to K dependent searches of ~6 global loads each on a single thread)
   if (!isdone) {
-    for (int rank = tid; rank < 2 * K; rank += 256) {
+    for (int rank = tid; rank < 2 * K; rank += NTHR) {
       int e = -1;
       if (rank < C) {
         const unsigned long long key = keys[rank];
@@ -436,14 +443,14 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
   __syncthreads();
 
   // advance sequences / ancestor table / per-row state (read old -> LDS -> write)
-  for (int idx = tid; idx < K * T; idx += 256) {
+  for (int idx = tid; idx < K * T; idx += NTHR) {
     const int j = idx / T, p = idx - j * T;
     int v = 0;
     if (p < cur_len) v = st.seq[(size_t)(row0 + sel_par[j]) * T + p];
     else if (p == cur_len) v = sel_tok[j];
     new_seq[idx] = v;
   }
-  for (int idx = tid; idx < T * K; idx += 256) {
+  for (int idx = tid; idx < T * K; idx += NTHR) {
     const int p = idx / K, j = idx - p * K;
     int v;
     if (p < t) v = st.anc[(size_t)p * R + row0 + sel_par[j]];
@@ -452,8 +459,8 @@ __global__ __launch_bounds__(256) void beam_step_kernel(gram_beam_state_t st, gr
     new_anc[idx] = v;
   }
   __syncthreads();
-  for (int idx = tid; idx < K * T; idx += 256) st.seq[(size_t)row0 * T + idx] = new_seq[idx];
-  for (int idx = tid; idx < T * K; idx += 256) {
+  for (int idx = tid; idx < K * T; idx += NTHR) st.seq[(size_t)row0 * T + idx] = new_seq[idx];
+  for (int idx = tid; idx < T * K; idx += NTHR) {
     const int p = idx / K, j = idx - p * K;
     st.anc[(size_t)p * R + row0 + j] = new_anc[idx];
   }
@@ -649,14 +656,23 @@ static int launch_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, 
   if (smem > 132 * 1024) return GRAM_E_ARG;
   static size_t attr_bytes = 0;
   if (smem > attr_bytes) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)smem);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_bytes = smem;
   }
   gram_prof::Scope prof(GRAM_K_BEAM, (hipStream_t)stream, 0.0);
-  hipLaunchKernelGGL(beam_step_kernel, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc,
-                     rows_per_user, (const bf16*)hd, (const bf16*)emb, d, rowpos, pieces, emb32);
+  // few users: one workgroup per user leaves the chip empty and the step is that workgroup's latency -> 1 024 threads per user
+  // (same per-candidate arithmetic, same total order of the keys: identical results; GRAM_BEAM_WIDE_MAXB: A/B hook, 0 = never)
+  static const int wide_max_b = getenv("GRAM_BEAM_WIDE_MAXB") ? atoi(getenv("GRAM_BEAM_WIDE_MAXB")) : 128;
+  if (st->B <= wide_max_b)
+    hipLaunchKernelGGL(beam_step_kernel<1024>, dim3(st->B), dim3(1024), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc,
+                       rows_per_user, (const bf16*)hd, (const bf16*)emb, d, rowpos, pieces, emb32);
+  else
+    hipLaunchKernelGGL(beam_step_kernel<256>, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc,
+                       rows_per_user, (const bf16*)hd, (const bf16*)emb, d, rowpos, pieces, emb32);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
