@@ -265,3 +265,20 @@ def test_runner_refuses_id_types_decoded_with_max_length_50():
         dataset = SimpleNamespace(all_items=["a b"], dataset="D", task="t")
     with pytest.raises(NotImplementedError):
         r._score_loader(L(loader))
+
+
+def test_error_codes_of_the_c_abi_map_to_messages():
+    """include/gram_hip.h's GRAM_E_* codes and the text GramHipError carries (the header is the contract: the numbers are read from it)."""
+    import re
+    from gram_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "gram_hip.h")).read()
+    codes = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (GRAM_E_\w+) \((-\d+)\)", hdr)}
+    assert codes == {"GRAM_E_ARG": _lib.E_ARG, "GRAM_E_WORKSPACE": _lib.E_WORKSPACE, "GRAM_E_BEAM": _lib.E_BEAM, "GRAM_E_NONFINITE": _lib.E_NONFINITE}
+    _lib.check(0, "ok")
+    for name, code in codes.items():
+        with pytest.raises(_lib.GramHipError, match=name):
+            _lib.check(code, "call")
+    with pytest.raises(_lib.GramHipError, match="bfloat16"):  # the way out of an activation overflow is named
+        _lib.check(_lib.E_NONFINITE, "gram_generate")
+    with pytest.raises(_lib.GramHipError, match="hipError 719"):
+        _lib.check(719, "call")
