@@ -231,6 +231,7 @@ def main():
     if prof:
         launches_per_step = 40 * (cfg.num_layers + cfg.num_decoder_layers * max_length) + 64
         _lib.check(lib.gram_prof_enable(sum(1 << k for k in kinds.values()), launches_per_step * args.steps), "prof_enable")
+    _lib.check(lib.gram_prof_pp_clock(None, 1), "pp_clock reset")  # (synchronises; outside the timed region)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -263,6 +264,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    pp_ghz = C.c_double(0.0)  # time-weighted in-kernel clock of the ping-pong GEMM launches of the timed region (gram_hip.h)
+    _lib.check(lib.gram_prof_pp_clock(C.byref(pp_ghz), 1), "pp_clock")
     kernel = {}
     if prof:
         for name, kind in kinds.items():
@@ -327,11 +330,12 @@ def main():
                      "mfma_products_per_product": NPROD[args.precision],
                      "note": "achieved = flops of the fp32 problem (2MNK) / time, priced against the dense 16-bit MFMA peak (2.5 PFLOP/s at 2.4 GHz); the "
                              "two-piece modes issue mfma_products_per_product MFMA products per product (achieved_mfma_executed); the native fp32 MFMA peak is 157 TFLOP/s",
-                     # in-kernel clock stamps of the ablation builds (make ABL=8, tests/bench_gemm_x3.py): the chip holds 1.52-1.78 GHz in these
-                     # kernels on random operands (power-limited), so the matrix peak it can be given is ~0.69 of the 2.4-GHz figure
-                     "clock_ghz_in_kernel": {"measured_range": [1.52, 1.78], "typical": 1.65, "source": "profiles/r03d_gemm_x3_ablation_and_clock.txt"},
-                     "peak_at_measured_clock": MFMA_BF16_PEAK_TF * 1.65 / 2.4,
-                     "frac_mfma_executed_at_measured_clock": gemm_exec_tf / (MFMA_BF16_PEAK_TF * 1.65 / 2.4),
+                     # the chip is power-limited in these kernels: every workgroup of the ping-pong GEMM stamps s_memtime / s_memrealtime around
+                     # its tile loop; this is the time-weighted clock over all their launches in the timed region (gram_prof_pp_clock), and the
+                     # matrix peak at THAT clock (per-shape table and ablations: profiles/r03d_gemm_x3_ablation_and_clock.txt)
+                     "clock_ghz_in_kernel": round(pp_ghz.value, 4) if pp_ghz.value > 0 else None,
+                     "peak_at_measured_clock": MFMA_BF16_PEAK_TF * pp_ghz.value / 2.4 if pp_ghz.value > 0 else None,
+                     "frac_mfma_executed_at_measured_clock": gemm_exec_tf / (MFMA_BF16_PEAK_TF * pp_ghz.value / 2.4) if pp_ghz.value > 0 else None,
                      "launches": gm["launches"], "avg_launch_us": 1e3 * gm["ms"] / max(gm["launches"], 1),
                      "share_of_kernel_time": gm["ms"] / max(sum(v["ms"] for v in kernel.values()), 1e-9)}
         roof_xa = {"kernel": "cross_attn_kernel", "bound": "hbm", "achieved": xa_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -125,6 +125,7 @@ SIGNATURES = {
     "gram_workspace_bytes": (i64, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gram_encode_fused": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, C.c_int, vp, vp]),
     "gram_decode_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
+    "gram_prof_pp_clock": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "gram_debug_set_gemm_variant": (C.c_int, [C.c_int]),
     "gram_gemm_stream_max_m": (C.c_int, []),
     "gram_debug_set_live_rows": (C.c_int, [C.c_int]),

@@ -45,7 +45,7 @@ namespace {
 #endif
 // Ablation builds of the ping-pong kernel (`make ABL=n` -> libgram_hip_abl<n>.so, loaded by tests/bench_gemm_x3.py through GRAM_LIB;
 // the product library is built with 0 and contains none of it).  Bits: 1 = no tile-end epilogue (results wrong), 2 = no operand DMA
-// after the prologue, 4 = no LDS fragment reads after the prologue, 8 = in-kernel clock stamps, 16 = the tile-end epilogue without its
+// after the prologue, 4 = no LDS fragment reads after the prologue, (8: was the clock stamps, now always on: gram_prof_pp_clock), 16 = the tile-end epilogue without its
 // global stores (fp32: without the stores, the bf16 copy and the partials; the residual loads stay).
 #ifndef GRAM_PP_ABL
 #define GRAM_PP_ABL 0
@@ -56,9 +56,11 @@ namespace {
 #ifndef GRAM_PP_INSL
 #define GRAM_PP_INSL 0  // A/B build hook: 1 = two-piece 16-bit outputs from inside the pipeline (measured: no gain, profiles/r03h, r03i)
 #endif
-#if GRAM_PP_ABL & 8  // + in-kernel clock stamps (MI355X_MICROARCH.md, DVFS item 6): per workgroup (shader cycles, 100-MHz ticks) around the tile loop
-__device__ unsigned long long g_pp_stamps[2 * 1024];
-#endif
+// In-kernel clock of the ping-pong GEMM (MI355X_MICROARCH.md, DVFS item 6): every workgroup stamps s_memtime (shader cycles) and
+// s_memrealtime (100-MHz ticks) around its tile loop and adds the two differences to these sums -- two atomics per workgroup and launch.
+// gram_prof_pp_clock() = sum / sum x 0.1 GHz: the time-weighted clock the chip held inside these kernels since the last reset (the MFMA
+// peak it can be priced against: the chip is power-limited in them).
+__device__ unsigned long long g_pp_clk[2];
 constexpr int BN = 128, BK = 64;
 
 enum { V_DMA_M64 = 31, V_DMA = 1, V_DMA_M256 = 3, V_PP = 22, V_RING_M64 = 33, V_RING_M128 = 34 };  // (ids kept from the variant table of round 1)
@@ -1742,8 +1744,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   zero_half(0);
   zero_half(1);
   abl_loop = true;
-#if GRAM_PP_ABL & 8
-  const unsigned long long abl_t0 = __builtin_amdgcn_s_memtime(), abl_r0 = __builtin_amdgcn_s_memrealtime();
+#ifndef GRAM_PP_NOCLK  // (A/B build hook: the kernel without its two clock stamps)
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   if constexpr (INSL) {
     const float *rs_cur = nullptr, *rs_prev = nullptr;
@@ -2082,10 +2084,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     tile += G;
   }
   }
-#if GRAM_PP_ABL & 8
-  if (tid == 0 && blockIdx.x < 1024) {
-    g_pp_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - abl_t0;
-    g_pp_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - abl_r0;
+#ifndef GRAM_PP_NOCLK
+  if (tid == 0) {
+    atomicAdd(&g_pp_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk_t0);
+    atomicAdd(&g_pp_clk[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0);
   }
 #endif
   // The last tile's m1 half is still in the accumulators.  Every DMA of this workgroup must have landed before it
@@ -2292,21 +2294,16 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
 
 }  // namespace
 
-#if GRAM_PP_ABL & 8
-// (ablation builds only, not part of the C ABI) the last ping-pong launch's in-kernel clock: out[0] = median GHz over its workgroups
-extern "C" int gram_debug_pp_clock(double* out, int nblocks) {
-  static unsigned long long h[2 * 1024];
-  if (nblocks < 1 || nblocks > 1024 || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pp_stamps), sizeof(h)) != hipSuccess) return GRAM_E_ARG;
-  double v[1024];
-  for (int i = 0; i < nblocks; ++i) v[i] = h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] * 0.1 : 0.0;
-  for (int i = 1; i < nblocks; ++i)
-    for (int j = i; j > 0 && v[j] < v[j - 1]; --j) { const double t = v[j]; v[j] = v[j - 1]; v[j - 1] = t; }
-  out[0] = v[nblocks / 2];
-  out[1] = v[0];
-  out[2] = v[nblocks - 1];
+extern "C" int gram_prof_pp_clock(double* ghz, int reset) {
+  unsigned long long h[2] = {0ull, 0ull};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pp_clk), sizeof(h)) != hipSuccess) return GRAM_E_ARG;  // (synchronises: not for a timed region)
+  if (ghz) *ghz = h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+  if (reset) {
+    const unsigned long long z[2] = {0ull, 0ull};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_pp_clk), z, sizeof(z)) != hipSuccess) return GRAM_E_ARG;
+  }
   return 0;
 }
-#endif
 
 extern "C" int gram_gemm_stream_max_m(void) { return g_force_variant < 0 ? stream_max_m() : 0; }
 

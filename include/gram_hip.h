@@ -438,6 +438,12 @@ int gram_prof_reset(void);
  * the recorded events.  dropped = launches not recorded because the pool was full. */
 int gram_prof_collect(int kind, double* total_ms, int64_t* launches, double* work, int64_t* dropped);
 
+/* Time-weighted shader clock (GHz) the chip held inside the persistent ping-pong GEMM launches since the last reset: every workgroup
+ * of those kernels adds its s_memtime / s_memrealtime differences around its tile loop to two device counters.  The MFMA peak a
+ * power-limited chip can be priced against is 2.5 PFLOP/s x this / 2.4 (bench.py's roofline).  Synchronises the device; reset != 0
+ * zeroes the counters after reading.  ghz may be NULL. */
+int gram_prof_pp_clock(double* ghz, int reset);
+
 /* Tuning hook: force a GEMM staging variant (0 = register-staged double buffer, 1 = LDS-DMA
  * single buffer, -1 = automatic per problem size).  Used by tests/bench_gemm.py. */
 int gram_debug_set_gemm_variant(int variant);

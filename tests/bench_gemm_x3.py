@@ -2,7 +2,8 @@
 uses, in EXECUTED MFMA TFLOP/s (3 products per logical product).
     python tests/bench_gemm_x3.py [--batch 4096] [--only "enc qkv"]
     GRAM_LIB=gram_amd/csrc/libgram_hip_abl1.so python tests/bench_gemm_x3.py     # ablation builds (make ABL=n; results not checked)
-ABL bits: 1 no tile-end epilogue, 2 no operand DMA after the prologue, 4 no LDS fragment reads, 8 in-kernel clock stamps."""
+ABL bits: 1 no tile-end epilogue, 2 no operand DMA after the prologue, 4 no LDS fragment reads, 16 the epilogue without its stores.
+Every line carries the time-weighted in-kernel clock of its launches (gram_prof_pp_clock)."""
 import argparse
 import ctypes as C
 import os
@@ -22,8 +23,6 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     lib = _lib.load()
-    abl = "abl" in os.environ.get("GRAM_LIB", "")
-    clock = getattr(lib, "gram_debug_pp_clock", None) if abl else None
     Me, Md = a.batch * 384, a.batch * 20
     d, F, V = 768, 3072, 32128
     shapes = [("enc qkv", Me, 3 * d, d, _lib.EPI_BF16), ("enc o", Me, d, d, _lib.EPI_F32_ADD), ("enc wi", Me, F, d, _lib.EPI_BF16_RELU),
@@ -59,6 +58,8 @@ def main():
             run = lambda: _lib.check(lib.gram_gemm_bf16_split(G.p(A), G.p(W), G.p(y), M, N, K, 2 * K, 2 * N if inter else N, epi, None, C.byref(nf), C.byref(sp), G.stream()), "bf16")
         for _ in range(2):
             run()
+        torch.cuda.synchronize()
+        _lib.check(lib.gram_prof_pp_clock(None, 1), "clock reset")
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(a.iters):
@@ -67,10 +68,9 @@ def main():
         torch.cuda.synchronize()
         us = s.elapsed_time(e) * 1e3 / a.iters
         line = f"{name:8s} M={M:8d} N={N:5d} K={K:4d}  {us:9.1f} us  {6.0 * M * N * K / us / 1e6:7.1f} TF executed"
-        if clock is not None:
-            out = (C.c_double * 3)()
-            if clock(out, 256) == 0:
-                line += f"  clock {out[0]:.3f} GHz (min {out[1]:.3f}, max {out[2]:.3f})"
+        ghz = C.c_double(0.0)
+        _lib.check(lib.gram_prof_pp_clock(C.byref(ghz), 1), "clock")
+        line += f"  in-kernel clock {ghz.value:.3f} GHz"
         print(line, flush=True)
         del A, W, keep
 
