@@ -446,3 +446,25 @@ def test_gemm_stream_matches_tiled(G, pieces, M, N, K):
         assert gemm(y, _lib.EPI_BF16, _lib.NormFusion(None, None, q_in.data_ptr(), K // 64, K, 1e-6, 1)) == _lib.E_ARG
     finally:
         L_.gram_debug_set_gemm_variant(-1)
+
+
+def test_pp_clock_counters(G):
+    """gram_prof_pp_clock: the ping-pong GEMM's workgroups add their s_memtime / s_memrealtime differences to two device counters; the
+    quotient is the shader clock in GHz (bench.py prices the MFMA peak at it).  Zero after a reset, a plausible clock after a launch."""
+    from gram_amd import _lib
+    L_ = G.lib()
+    ghz = C.c_double(-1.0)
+    _lib.check(L_.gram_prof_pp_clock(C.byref(ghz), 1), "clock")
+    _lib.check(L_.gram_prof_pp_clock(C.byref(ghz), 0), "clock")
+    assert ghz.value == 0.0
+    M, N, K = 256 * 160, 512, 256
+    a32, w32 = _r(M, K, seed=1).to(G.DEV), _r(N, K, seed=2, scale=K ** -0.5).to(G.DEV)
+    y = torch.zeros(M, 2 * N, dtype=G.DT, device=G.DEV)
+    try:
+        L_.gram_debug_set_gemm_variant(22)
+        _lib.check(split_gemm(G, G.inter(a32), G.inter(w32), y, M, N, K, _lib.EPI_BF16, True, 0), "pp gemm")
+    finally:
+        L_.gram_debug_set_gemm_variant(-1)
+    _lib.check(L_.gram_prof_pp_clock(C.byref(ghz), 1), "clock")
+    print(f"\n[pp clock] {ghz.value:.3f} GHz")
+    assert 0.4 < ghz.value < 2.6, ghz.value
