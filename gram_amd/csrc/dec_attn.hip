@@ -63,8 +63,13 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     const int32_t* __restrict__ rowpos, long q_pstride, long bank_pstride, const uint32_t* __restrict__ key_bits) {
   using T = SplitTab<S>;
   constexpr int NB = NT * 16;                     // padded beams
-  constexpr int STAGE = S * 2 * XA_TILE;          // per wave and ring slot: S x (K tile | V^T tile)
-  constexpr int RING = R * STAGE;
+  // R == 0: "half slot" -- ONE region per wave that holds a step's K tiles, then (once their fragments are in registers) its V^T tiles,
+  // then the next step's K tiles ...: half the LDS per workgroup, twice the workgroups per CU to cover each other's prologue and merge
+  constexpr bool HALF = R == 0;
+  constexpr int PSTR = HALF ? XA_TILE : 2 * XA_TILE;  // piece stride inside a slot
+  constexpr int VOFF = HALF ? 0 : XA_TILE;           // V^T tiles: behind the K tiles, or in their place
+  constexpr int STAGE = S * PSTR;                     // per wave and ring slot: S x (K tile | V^T tile)
+  constexpr int RING = (HALF ? 1 : R) * STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm_m = reinterpret_cast<float*>(smem);   // [NW][NB]     (the merge buffers alias the rings)
   float* sm_l = sm_m + NW * NB;                   // [NW][NB]
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     for (int mt = 0; mt < 4; ++mt) o[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  if constexpr (R == 1) {
+  if constexpr (R <= 1) {
     // query fragments: requested first, in parallel with the key bits, and retired with them by the wait in front of the ring --
     // the counted waits of the half-stage loop must see DMA instructions only
 #pragma unroll
@@ -175,8 +180,8 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
       const char* kbase = kb + (size_t)pc * bank_pstride * 2 + (size_t)step * (32 * 128);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if constexpr ((GRAM_XA_NT & 1) != 0) dma16_nt(dst + pc * 2 * XA_TILE + i * 1024, koff[i], kbase);
-        else dma16(dst + pc * 2 * XA_TILE + i * 1024, koff[i], kbase);
+        if constexpr ((GRAM_XA_NT & 1) != 0) dma16_nt(dst + pc * PSTR + i * 1024, koff[i], kbase);
+        else dma16(dst + pc * PSTR + i * 1024, koff[i], kbase);
       }
     }
   };
@@ -187,8 +192,8 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
       const char* vbase = vt + (size_t)pc * bank_pstride * 2 + (size_t)step * 4096;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if constexpr ((GRAM_XA_NT & 2) != 0) dma16_nt(dst + pc * 2 * XA_TILE + XA_TILE + i * 1024, voff[i], vbase);
-        else dma16(dst + pc * 2 * XA_TILE + XA_TILE + i * 1024, voff[i], vbase);
+        if constexpr ((GRAM_XA_NT & 2) != 0) dma16_nt(dst + pc * PSTR + VOFF + i * 1024, voff[i], vbase);
+        else dma16(dst + pc * PSTR + VOFF + i * 1024, voff[i], vbase);
       }
     }
   };
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
 #pragma unroll
         for (int kd = 0; kd < 2; ++kd) {
           const int r = krow + 4 * t;
-          kf[pc][t][kd] = *reinterpret_cast<const bf16x8*>(stg + pc * 2 * XA_TILE + r * 128 + (((g + 4 * kd) ^ ksw(r)) << 4));
+          kf[pc][t][kd] = *reinterpret_cast<const bf16x8*>(stg + pc * PSTR + r * 128 + (((g + 4 * kd) ^ ksw(r)) << 4));
         }
   };
   auto read_v = [&](int slot) {
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int d = 16 * mt + c;
-        vf[pc][mt] = *reinterpret_cast<const bf16x8*>(stg + pc * 2 * XA_TILE + XA_TILE + d * 64 + ((g ^ vsw(d)) << 4));
+        vf[pc][mt] = *reinterpret_cast<const bf16x8*>(stg + pc * PSTR + VOFF + d * 64 + ((g ^ vsw(d)) << 4));
       }
   };
   auto read_frags = [&](int slot) {
@@ -293,7 +298,32 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
   // DMA instructions only.  The query fragments are loaded AFTER the ring is primed: their latency hides behind the first stages
   // (hipcc waits for them with vmcnt(0) at their first use, which the first stage has to reach anyway).
   wait_vm<0>();
-  if constexpr (R == 1) {
+  if constexpr (HALF) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int pc = 0; pc < S; ++pc)
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd) asm volatile("" : "+v"(qf[pc][nt][kd]));
+    // half slot: K(s) -> fragments -> V(s) into the same region (in flight during S^T / softmax) -> fragments -> K(s+1) (in flight during
+    // O^T += V^T P^T) ...: one half-stage in flight per wave, twice the waves per CU
+    int cur = next(-1);
+    if (cur < nsteps) issue_k(0, cur);
+    while (cur < nsteps) {
+      const int nxt = next(cur);
+      wait_vm<0>();
+      read_k(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the K fragments are in registers before the region is re-filled
+      issue_v(0, cur);
+      math_qk(cur);
+      wait_vm<0>();
+      read_v(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (nxt < nsteps) issue_k(0, nxt);
+      math_pv();
+      cur = nxt;
+    }
+  } else if constexpr (R == 1) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
 #endif
       cur = nxt;
     }
-  } else {
+  } else if constexpr (R >= 2) {
     // ring of R stages: rq[i] = step held by slot i; `head` is the oldest.  All scalar state.
     int rq[R];
     int head = 0, inflight = 0, last = -1;
@@ -479,7 +509,7 @@ template <int NT, int S, int NW, int R>
 int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int Sk,
                  const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, const uint32_t* key_bits, hipStream_t st) {
   constexpr int NB = NT * 16;
-  constexpr int ring = NW * R * S * 2 * XA_TILE, merge = NW == 1 ? 0 : (2 * NW * NB + NW * NB * 64) * 4;
+  constexpr int ring = NW * (R == 0 ? S * XA_TILE : R * S * 2 * XA_TILE), merge = NW == 1 ? 0 : (2 * NW * NB + NW * NB * 64) * 4;
   constexpr int smem = ring > merge ? ring : merge;
   static_assert(smem <= 160 * 1024, "ring does not fit the LDS");
   static bool attr_set = false;
@@ -547,6 +577,9 @@ int launch_cross_v(const void* q, const void* k, const void* vt, const uint8_t* 
       case 13: return launch_cross<NT, S, 1, 3>(XA_ARGS);
       case 14: return launch_cross<NT, S, 1, 4>(XA_ARGS);
       case 21: return launch_cross<NT, S, 2, 1>(XA_ARGS);
+      case 20: return launch_cross<NT, S, 2, 0>(XA_ARGS);
+      case 10: return launch_cross<NT, S, 1, 0>(XA_ARGS);
+      case 40: return launch_cross<NT, S, 4, 0>(XA_ARGS);
       default: break;
     }
   }
@@ -557,6 +590,8 @@ int launch_cross_v(const void* q, const void* k, const void* vt, const uint8_t* 
   // (three or four beam tiles, K > 32: the per-workgroup state is larger and one wave per (user, head) with two stages wins --
   // K = 50, S = 2 688, H = 16: (1, 2) 4.32 / 5.28 TB/s against (2, 1) 3.93 / 4.99, (2, 2) 4.08 / 4.95, (4, 1) 3.66 / 4.75)
   // (a ring of 3 stages per wave for grids of a handful of users was measured too: 12.42 -> 12.67 ms per one-user generate, no gain)
+  // (round 3, R = 0 "half slot": one 8-KB region per wave for a step's K tiles, then its V^T tiles -- half the LDS, twice the workgroups per
+  // CU: (2, 0) 5.80, (1, 0) 5.80, (4, 0) 5.77 TB/s against 5.75-5.94 for (2, 1) in the same run: no gain, profiles/r03_cross_attn_half_slot_ab.txt)
   // (with the stage consumed and re-filled in halves, ONE stage wins there too: K = 50, S = 2 688, H = 16, same box: (1, 1) 4.65 / 5.75 TB/s
   // against (1, 2) 3.97 / 5.12, (4, 1) 4.19 / 5.37, (2, 2) 3.72 / 5.02 -- profiles/r02m_cross_attn_k50_variants.txt)
   if constexpr (NT >= 3) return launch_cross<NT, S, 1, 1>(XA_ARGS);
