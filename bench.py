@@ -72,6 +72,8 @@ def parse():
                          "depend on the passages as a trained model's do and the last step keeps the few percent of live rows the Trie implies")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements of the N = 1 run (all-rows decode, B = 1 latency, the other precision modes)")
+    ap.add_argument("--e2e-users", type=int, default=22363,
+                    help="users of the synthetic dataset directory the drop-in runner scores end to end in `extras` (Beauty has 22 363; 0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--ragged", action="store_true",
                     help="realistic batch: passage counts drawn from the dataset's histogram (padded to --passages), valid "
@@ -113,6 +115,43 @@ def spawn_ranks(args):
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     return max(abs(c) for c in codes)
+
+
+def e2e_runner(model, dev, n_users):
+    """users/s of ``get_runner("single", ...).test()`` on a generated Beauty-sized dataset directory, reference default flags."""
+    import shutil
+    import tempfile
+
+    from gram_amd.runner import get_runner
+    from tools import synth_dataset as SD
+
+    root = tempfile.mkdtemp(prefix="gram_e2e_")
+    try:
+        a = SD.make(root, n_users=n_users)
+        runner = get_runner("single", model, None, SD.SynthTokenizer(), None, None, None, dev, a)
+        runs = []
+        for _ in range(2):  # the second run is the steady state of a process (weights packed, workspace allocated)
+            model.clear_passage_cache()  # every evaluation pays for its own passage-cache fill
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            runner.test(None)  # rebuilds the loaders like the reference (single_runner_gram.py:370-375), then scores
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            r = runner.last_results
+            runs.append({"users": r["total"], "test_call_s": round(wall, 3), "score_loader_s": round(r["score_loader_seconds"], 3),
+                         "generate_s": round(r["generate_seconds"], 3), "users_per_call": runner.last_host["users_per_call"],
+                         "host_phases_s": {k: round(v, 3) for k, v in runner.last_host.get("phases", {}).items()}})
+        r = runs[-1]
+        return {"users_per_s_end_to_end": r["users"] / r["score_loader_s"], "users_per_s_generate_only": r["users"] / r["generate_s"],
+                "users_per_s_test_call_incl_dataset_load": r["users"] / r["test_call_s"],
+                "end_to_end_over_generate_only": r["generate_s"] / r["score_loader_s"],
+                "host_ms_per_batch_not_overlapped": 1e3 * (r["score_loader_s"] - r["generate_s"]) / max(1, -(-r["users"] // r["users_per_call"])),
+                "flags": "--eval_batch_size 1 (reference default), --max_his 2, beam 20, passage cache on; generate-only = the sum of the "
+                         "generate() calls, the quantity the reference logs (single_runner_gram.py:640-652,712-714); end-to-end = "
+                         "test_dataset_task: candidates -> Trie -> passage cache -> collate -> H2D -> generate -> strings -> metrics",
+                "runs": runs}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def main():
@@ -434,6 +473,14 @@ def main():
                     extras["users_per_s_other_modes"][mode] = f"failed at B={Bm}: {str(ex)[:60]}"
         model.set_precision(args.precision)
         model._workspace = None
+        # (4) SURVEY.md §8(d)'s second metric: end-to-end users/s of the DROP-IN RUNNER -- get_runner("single").test() as
+        # main_generative_gram.py:107-127 calls it, with the reference's default --eval_batch_size 1 -- on a synthetic dataset
+        # directory of Beauty's size (tools/synth_dataset.py: the real 12 101-item Trie, 22 363 users, N = 3 passages of 128 tokens)
+        if (N, L, K) == (3, 128, 20) and args.dataset == "Beauty" and args.e2e_users > 0:
+            try:
+                extras["e2e_runner"] = e2e_runner(model, dev, args.e2e_users)
+            except Exception as ex:  # secondary measurement: never costs the headline line
+                extras["e2e_runner"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
         result["extras"] = extras
 
     if state is not None:

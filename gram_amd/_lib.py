@@ -18,7 +18,7 @@ GRAM_MAX_PASSAGE_LEN = 128
 EPI_BF16, EPI_BF16_RELU, EPI_F32_ADD, EPI_F32, EPI_KV_BANK = range(5)
 K_GEMM, K_ENC_ATTN, K_CROSS_ATTN, K_DEC_SELF_ATTN, K_ROWOPS, K_LSE, K_BEAM = range(7)
 E_ARG, E_WORKSPACE, E_BEAM, E_NONFINITE = -1, -2, -3, -4
-ABI_VERSION = 5
+ABI_VERSION = 6
 # two-piece mode (gram_hip.h, gram_split_t): 16-bit pieces per value -> MFMA products per product
 MAX_PIECES = 2
 SPLIT_NPROD = (0, 1, 3)
@@ -120,6 +120,7 @@ SIGNATURES = {
     "gram_greedy_step": (C.c_int, [C.POINTER(BeamState), C.POINTER(Trie), vp, C.c_int, C.c_int, vp]),
     "gram_greedy_finalize": (C.c_int, [C.POINTER(BeamState), C.c_int, vp, vp, vp]),
     "gram_beam_finalize": (C.c_int, [C.POINTER(BeamState), C.c_int, C.c_int, vp, vp, vp, vp]),
+    "gram_trie_item_index": (C.c_int, [C.POINTER(Trie), vp, vp, C.c_int, C.c_int, vp, vp]),
     "gram_model_create": (vp, [C.POINTER(ModelDesc)]),
     "gram_model_destroy": (None, [vp]),
     "gram_workspace_bytes": (i64, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

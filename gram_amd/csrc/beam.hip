@@ -57,6 +57,9 @@ __device__ void hyp_add(const gram_beam_state_t& st, int b, const int32_t* toks,
   int32_t* ht = st.hyp_tok + (size_t)b * (K + 1) * T;
   int n = st.n_hyps[b];
   const double score = (double)sum_logprobs / norm_len(len, st.length_penalty);
+  // a NaN would lose every comparison below (never kept once the heap is full, evicted first otherwise) and vanish silently; +inf cannot
+  // be a sum of log-probabilities: both mean an activation left the range of the 16-bit pieces upstream (GRAM_E_NONFINITE)
+  if (!(score < 1.0e300)) st.error[0] = 4;
   if (n < K || score > st.worst[b]) {
     hs[n] = score;
     hl[n] = len;
@@ -321,6 +324,18 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
     __syncthreads();
   }
   if (!isdone) {
+    // Non-finite arithmetic is flagged HERE, at its source (GRAM_E_NONFINITE), not at the returned scores: a NaN candidate sorts above
+    // +inf (positive NaN) or below -inf (negative NaN) and would be picked first or never, a row whose normaliser is +inf / NaN turns
+    // all its candidates into -inf / NaN -- either way the search would go on and return an ordinary-looking ranking without them.
+    // -inf candidates are legitimate (HF's -inf refills of finished beams).
+    for (int ci = tid; ci < C; ci += NTHR) {
+      const uint32_t o = (uint32_t)(keys[ci] >> 32);
+      if (o >= 0xff800000u || o < 0x007fffffu) st.error[0] = 4;  // f2ord(+inf) = 0xff800000, f2ord(-inf) = 0x007fffff
+    }
+    if (tid < K && s_cnt[tid] > 0) {
+      const int lr = rows_per_user == 1 ? b : s_lr[tid];
+      if (lr >= 0 && !(fabsf(lse[lr]) < 3.0e38f)) st.error[0] = 4;
+    }
     // Only the best 2K candidates are looked at (topk(2K) in beam_search), in descending order: a bitonic TOP-P
     // selection, P = the power of two >= 2K.  Sort every P-block (directions alternating, as in a full bitonic sort
     // stopped at stage P), then halve the array round by round: a descending block followed by an ascending one is a
@@ -626,6 +641,31 @@ __global__ void greedy_finalize_kernel(gram_beam_state_t st, int max_length, int
   atomicMax(out_width, len);
 }
 
+// Item index of every returned sequence: a hypothesis of a Trie-constrained search is a root-to-leaf path, so walking the CSR
+// from the root along the sequence's tokens (start token first) ends on a leaf, and node_item[leaf] is the candidate it spells.
+// -1: the row is not a candidate (the -inf filler beams HF pads a user with when fewer than nret hypotheses finished).
+__global__ void trie_item_index_kernel(gram_trie_t tr, const int32_t* __restrict__ node_item, const int64_t* __restrict__ sequences,
+                                       int rows, int T, int pad, int32_t* __restrict__ out_item) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int64_t* seq = sequences + (size_t)r * T;
+  int node = 0, p = 0;
+  for (; p < T; ++p) {
+    if (tr.child_off[node + 1] == tr.child_off[node]) break;  // a leaf: the candidate is complete
+    const int64_t tok = seq[p];
+    const int e = (tok < 0 || tok > 0x7fffffff) ? -1 : find_child(tr, node, (int)tok);
+    if (e < 0) { node = -1; break; }
+    node = tr.child_node[e];
+  }
+  int item = -1;
+  if (node > 0 && tr.child_off[node + 1] == tr.child_off[node]) {
+    item = node_item[node];
+    for (; p < T; ++p)  // what follows a candidate is padding, or the row is some other sequence that merely starts like one
+      if (seq[p] != pad) item = -1;
+  }
+  out_item[r] = item;
+}
+
 }  // namespace
 
 static int check_state(const gram_beam_state_t* st) {
@@ -742,6 +782,16 @@ extern "C" int gram_beam_finalize(const gram_beam_state_t* st, int nret, int max
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(beam_finalize_kernel, dim3(st->B), dim3(64), 0, (hipStream_t)stream, *st, nret, max_length, max_length,
                      sequences, scores, out_width);
+  GRAM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int gram_trie_item_index(const gram_trie_t* tr, const int32_t* node_item, const int64_t* sequences, int rows, int T,
+                                    int32_t* out_item, void* stream) {
+  if (!tr || !tr->child_off || !node_item || !sequences || !out_item || rows < 0 || T < 1 || tr->n_nodes < 1) return GRAM_E_ARG;
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(trie_item_index_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, *tr, node_item, sequences, rows,
+                     T, /*pad=*/0, out_item);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

@@ -131,10 +131,11 @@ class GRAM(nn.Module):
         self._version = 0
         self._workspace = None
         self._tries: Dict[int, tuple] = {}  # id(trie) -> (trie, FlatTrie)
-        # The reference computes in fp32; "bf16x3" is the cheapest arithmetic that keeps Recall@5 / NDCG@5 within 1e-4 of it
-        # (DESIGN.md §5), so it is what a drop-in model starts in.  GRAM_PRECISION / set_precision() choose another.
-        self._precision = os.environ.get("GRAM_PRECISION", self.default_precision())
-        if self._precision not in self.PRECISIONS:
+        # The reference computes in fp32; "f16x3" (two IEEE-half pieces per value, three MFMA products per product) is the cheapest
+        # arithmetic that keeps Recall@5 / NDCG@5 within 1e-4 of it, so it is what a drop-in model starts in.
+        # GRAM_PRECISION / set_precision() choose another.
+        self._precision = os.environ.get("GRAM_PRECISION") or None  # None: the loaded library's default, resolved at first use
+        if self._precision is not None and self._precision not in self.PRECISIONS:
             raise ValueError(f"GRAM_PRECISION={self._precision!r}: choose from {self.PRECISIONS}")
         self._pcache = None  # passage cache: dict(x, canon, keys, perm) on the device
         self._stage_caps: Dict[str, int] = {}  # sensitivity sweeps only (set_stage_pieces)
@@ -179,16 +180,22 @@ class GRAM(nn.Module):
             remapped[k] = v
         return self.load_state_dict(remapped, strict=False)
 
-    # "bf16": bf16 operands (8 significant bits).  "bf16x3" / "bf16x6": every value travels as 2 / 3 bf16 pieces and every
-    # product is 3 / 6 bf16 MFMA products (gram_hip.h, gram_split_t): ~2^-18 / fp32-class relative error at 3x / 6x the MFMA work.
-    # The 16-bit type is a property of the library build (gram_piece_format(): libgram_hip.so on bfloat16, PIECE=f16 builds on IEEE
-    # half -- 11 significant bits per piece, ~2^-22 for two pieces); the mode's prefix must name the loaded library's type.
+    # "f16" / "bf16": one 16-bit piece per value (11 / 8 significant bits).  "f16x3" / "bf16x3": every value travels as two pieces and
+    # every product is three MFMA products (gram_hip.h, gram_split_t): ~2^-22 / ~2^-18 relative error at 3x the MFMA work.
+    # The 16-bit type is a property of the library build (gram_piece_format(): libgram_hip.so, the default build, computes on IEEE
+    # half; `make PIECE=bf16` builds libgram_hip_bf16.so on bfloat16); the mode's prefix must name the loaded library's type.
     PRECISIONS = ("bf16", "bf16x3", "f16", "f16x3")
     _PIECES = {"bf16": 1, "bf16x3": 2, "f16": 1, "f16x3": 2}
 
     @staticmethod
     def default_precision() -> str:
         return "f16x3" if _lib.load().gram_piece_format() == 1 else "bf16x3"
+
+    @property
+    def precision(self) -> str:
+        if self._precision is None:
+            self._precision = self.default_precision()
+        return self._precision
 
     def set_precision(self, mode: str) -> None:
         """Arithmetic of the GEMM / attention operands (accumulation, residual stream, softmax and scores are fp32 in
@@ -270,10 +277,10 @@ class GRAM(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        pieces = self._PIECES[self._precision]
+        pieces = self._PIECES[self.precision]
         f16 = lib.gram_piece_format() == 1
-        if self._precision.startswith("f16") != f16:
-            raise _lib.GramHipError(f"precision {self._precision!r} needs the {'f16' if not f16 else 'bf16'} build of libgram_hip "
+        if self.precision.startswith("f16") != f16:
+            raise _lib.GramHipError(f"precision {self.precision!r} needs the {'f16' if not f16 else 'bf16'} build of libgram_hip "
                                     f"(loaded: {_lib.LIB_PATH}; GRAM_LIB selects another build)")
         tdt = torch.float16 if f16 else torch.bfloat16
         w_scales = []
@@ -402,6 +409,30 @@ class GRAM(nn.Module):
             self._workspace = None
             self._workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
         return self._workspace
+
+    def max_users_per_call(self, N: int, L: int, K: int, max_length: int, limit: int = 4096, headroom: float = 0.9) -> int:
+        """Largest batch B <= limit whose ``generate`` workspace (gram_workspace_bytes) fits the device's free HBM: what the runners
+        size their GPU batches with, whatever ``--eval_batch_size`` the loader was built with (results do not depend on the batch a
+        user is scored in).  Memory held by this model's current workspace counts as free (it is re-used or replaced)."""
+        handle = self._pack()
+        lib = _lib.load()
+        dev = self._device()
+        Lp = (int(L) + 31) // 32 * 32
+        free, _total = torch.cuda.mem_get_info(dev)
+        if self._workspace is not None and self._workspace.device == dev:
+            free += self._workspace.numel()
+        budget = int(free * headroom)
+        lo, hi = 1, max(1, int(limit))
+        if lib.gram_workspace_bytes(handle, hi, N, Lp, K, max_length) <= budget:
+            return hi
+        while lo < hi:  # workspace bytes grow monotonically with B
+            mid = (lo + hi + 1) // 2
+            need = lib.gram_workspace_bytes(handle, mid, N, Lp, K, max_length)
+            if 0 <= need <= budget:
+                lo = mid
+            else:
+                hi = mid - 1
+        return lo
 
     @staticmethod
     def _closure_trie(fn: Callable):
@@ -603,6 +634,24 @@ class GRAM(nn.Module):
         if not return_dict_in_generate:
             return seqs
         return GenerateOutput(sequences=seqs, sequences_scores=scores)
+
+    @torch.no_grad()
+    def sequence_items(self, sequences, prefix_allowed_tokens_fn, candidates):
+        """Which candidate each row of ``generate(...)["sequences"]`` spells: int32 (rows,) indices into ``candidates`` -- the
+        token-id sequences the closure's Trie was built from, in the caller's order -- or -1 for a row that is not a candidate
+        (HF's -inf filler beams).  Every hypothesis of a Trie-constrained search is a leaf of the Trie, so the runner needs one
+        ``batch_decode`` of the candidate list per evaluation instead of one of B*K generated rows per batch
+        (single_runner_gram.py:657-662); ``gram_trie_item_index`` walks the flat Trie on the device."""
+        flat = self._flat_trie(prefix_allowed_tokens_fn)
+        dev = self._device()
+        ctrie, _keep = flat.to_device(dev)
+        node_item = flat.node_items_on(dev, candidates)
+        seqs = sequences.to(dev, torch.int64).contiguous()
+        out = torch.empty(seqs.shape[0], dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().gram_trie_item_index(C.byref(ctrie), node_item.data_ptr(), seqs.data_ptr(), seqs.shape[0], seqs.shape[1],
+                                                        out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "gram_trie_item_index")
+        return out
 
     def _generate_with_callback(self, ids, mask, B, N, Lp, K, nret, max_length, length_penalty, fn, return_dict):
         """Slow path for an ARBITRARY ``prefix_allowed_tokens_fn(batch_id, sent) -> List[int]`` (HF's

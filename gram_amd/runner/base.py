@@ -24,6 +24,33 @@ def _arg(args, name, default):
     return getattr(args, name, default) if args is not None else default
 
 
+class _PredRows:
+    """Per-user (gold string, K predicted strings in the order generate returned them, K scores) rows, materialised on demand:
+    an evaluation keeps item indices and scores, the strings come from the candidate list's one decode."""
+
+    def __init__(self, gold, items, scores, extra, cand_str, K):
+        self.gold, self.items, self.scores, self.extra, self.cand_str, self.K = gold, items, scores, extra, cand_str, K
+
+    def __len__(self):
+        return len(self.gold)
+
+    def __iter__(self):
+        u = 0
+        for items, scores, extra in zip(self.items, self.scores, self.extra):
+            for b in range(items.shape[0]):
+                gen = [self.cand_str[i] if i >= 0 else extra[b * self.K + k] for k, i in enumerate(items[b].tolist())]
+                yield self.gold[u], gen, scores[b]
+                u += 1
+
+    def head(self, n):
+        out = []
+        for row in self:
+            if len(out) >= n:
+                break
+            out.append(row)
+        return out
+
+
 class BaseRunner:
     def __init__(self, model_rec, model_gen, tokenizer, train_loader_id, train_loader_rec, valid_loader, device, args):
         self.model = model_rec
@@ -110,16 +137,6 @@ class BaseRunner:
                 out.append([0] + self.tokenizer.encode(f"{cand}"))
         return out
 
-    def _decode(self, ids: torch.Tensor) -> List:
-        """batch_decode(skip_special_tokens=True) when a tokenizer exists, else id tuples with the
-        specials (pad 0, eos 1, -100 label padding) dropped -- the same equality relation whenever
-        decoding is injective on the candidate set."""
-        rows = ids.detach().cpu().tolist()
-        if self.tokenizer is not None:
-            rows = [[t for t in r if t >= 0] for r in rows]
-            return self.tokenizer.batch_decode(rows, skip_special_tokens=True)
-        return [tuple(t for t in r if t > 1) for r in rows]
-
     def _load(self, path: Optional[str], strict: bool = True) -> None:
         if path:
             if os.path.isdir(path):
@@ -148,13 +165,114 @@ class BaseRunner:
         logging.info(f"passage cache: {n} item prompts encoded in {time() - start:.2f}s")
         return n
 
+    # ---------------------------------------------------------------- GPU batches, whatever --eval_batch_size is
+    def _gpu_batch_users(self, model, n_slots: int, L: int, K: int, max_length: int) -> int:
+        """Users per ``generate`` call.  The reference scores `--eval_batch_size` users per call (default 1,
+        arguments.py:84-86): 95 users/s on this path against 3 100 at 4 096 per call.  A user's result does not depend on the batch
+        it is scored in (bit for bit: tests/test_gpu_configs.py), so the runner re-batches: `--eval_gpu_batch` / GRAM_EVAL_USERS
+        users per call, default the largest count <= 4 096 whose workspace fits the free HBM."""
+        explicit = int(_arg(self.args, "eval_gpu_batch", 0) or os.environ.get("GRAM_EVAL_USERS", 0) or 0)
+        if explicit > 0:
+            return explicit
+        if hasattr(model, "max_users_per_call"):
+            return int(model.max_users_per_call(n_slots, L, K, max_length, limit=4096))
+        return 4096
+
+    @staticmethod
+    def _merge_batches(parts):
+        """Collated batches -> one: passages padded like the Collator pads them (all-zero ids, all-False mask; Collator.py:410-436),
+        targets with -100."""
+        if len(parts) == 1:
+            return parts[0]
+        B = sum(p["item_text_ids"].shape[0] for p in parts)
+        N = max(p["item_text_ids"].shape[1] for p in parts)
+        L = max(p["item_text_ids"].shape[2] for p in parts)
+        T = max(p["target_ids"].shape[1] for p in parts)
+        ids = torch.zeros(B, N, L, dtype=parts[0]["item_text_ids"].dtype)
+        mask = torch.zeros(B, N, L, dtype=torch.bool)
+        tgt = torch.full((B, T), -100, dtype=parts[0]["target_ids"].dtype)
+        users, lo = [], 0
+        for p in parts:
+            b, n, l = p["item_text_ids"].shape
+            ids[lo:lo + b, :n, :l] = p["item_text_ids"]
+            mask[lo:lo + b, :n, :l] = p["item_text_masks"].bool()
+            tgt[lo:lo + b, : p["target_ids"].shape[1]] = p["target_ids"]
+            users += list(p.get("user_ids", [None] * b))
+            lo += b
+        return {"item_text_ids": ids, "item_text_masks": mask, "target_ids": tgt, "user_ids": users}
+
+    def _gpu_batches(self, testloader, users_per_call: int):
+        """The loader's users, in the loader's order, `users_per_call` at a time.  A loader built by this runner (map-style dataset,
+        batch sampler, CollatorGRAM) is read through its batch sampler and collated once per GPU batch; any other loader is iterated
+        as it is and its collated batches are merged."""
+        bs = getattr(testloader, "batch_sampler", None)
+        collate = getattr(testloader, "collate_fn", None)
+        data = getattr(testloader, "dataset", None)
+        if bs is not None and collate is not None and hasattr(data, "__getitem__") and getattr(testloader, "num_workers", 0) == 0 \
+                and not isinstance(data, torch.utils.data.IterableDataset):
+            pending = []
+            for idx in bs:
+                pending.extend(idx)
+                while len(pending) >= users_per_call:
+                    take, pending = pending[:users_per_call], pending[users_per_call:]
+                    yield collate([data[i] for i in take])
+            if pending:
+                yield collate([data[i] for i in pending])
+            return
+        parts, n = [], 0
+        for batch in testloader:
+            parts.append(batch)
+            n += batch["item_text_ids"].shape[0]
+            if n >= users_per_call:
+                yield self._merge_batches(parts)
+                parts, n = [], 0
+        if parts:
+            yield self._merge_batches(parts)
+
+    def _decode_rows(self, rows) -> List:
+        """batch_decode(skip_special_tokens=True) when a tokenizer exists, else id tuples with the
+        specials (pad 0, eos 1, -100 label padding) dropped -- the same equality relation whenever
+        decoding is injective on the candidate set."""
+        if self.tokenizer is not None:
+            rows = [[t for t in r if t >= 0] for r in rows]
+            return self.tokenizer.batch_decode(rows, skip_special_tokens=True)
+        return [tuple(t for t in r if t > 1) for r in rows]
+
+    def _decode(self, ids: torch.Tensor) -> List:
+        return self._decode_rows(ids.detach().cpu().tolist())
+
     def _score_loader(self, testloader):
-        """Per-user hit ranks for one loader: (ranks int16 [n], total generate() seconds, examples)."""
+        """Per-user hit ranks for one loader: (ranks int16 [n], total generate() seconds, examples, user ids, pred rows).
+
+        The reference's loop body (single_runner_gram.py:622-694) per batch: collate -> H2D -> generate -> batch_decode of the B*K
+        generated rows and of the targets -> rel_results -> metrics.  Here, with the same results:
+          * users are scored `_gpu_batch_users` at a time whatever --eval_batch_size is (see there);
+          * every generated row is a leaf of the candidate Trie, so the device returns the ITEM INDEX of each row
+            (GRAM.sequence_items -> gram_trie_item_index) and the strings come from ONE batch_decode of the candidate list per
+            evaluation -- the string of a row depends on its ids alone, so these are the strings the reference decodes per batch;
+            rows that are not candidates (HF's -inf filler beams) are decoded individually, like the reference decodes every row;
+          * string equality is evaluated on integer ids of the distinct strings (evaluate.hit_ranks_from_ids);
+          * collating batch i+1 and post-processing batch i-1 overlap generate() of batch i (two worker threads; the C-ABI call
+            releases the GIL)."""
+        import queue
+        import threading
+
+        phases = {}
+        t_phase = time()
+
+        def lap(name):
+            nonlocal t_phase
+            now = time()
+            phases[name] = phases.get(name, 0.0) + now - t_phase
+            t_phase = now
+
         self._warm_passage_cache(testloader)
+        lap("passage_cache")
         candidates = testloader.dataset.all_items
         encoded = self.encode_candidates(candidates)
         trie = gt.Trie(encoded)
         fn = gt.prefix_allowed_tokens_fn(trie)
+        lap("candidates_and_trie")
         # single_runner_gram.py:633-641, hoisted out of the loop: the longest candidate for the "t5_token" / "split" id types.  The
         # reference passes max_length = 50 for every other id type; the kernels stop at GRAM_MAX_DEC_LEN = 32 and a clamp to the Trie's
         # depth equals HF's result only when every user has K finished hypotheses by then (otherwise HF keeps decoding -inf beams to
@@ -165,31 +283,126 @@ class BaseRunner:
                                       "build implements the 't5_token' and 'split' id types" % _arg(self.args, "item_id_type", None))
         K = self.generate_num
         model = self._generate_model()
-        ranks, user_ids, examples, total_time = [], [], [], 0.0
-        rows_out = []
-        with torch.no_grad():
-            for batch in testloader:
-                input_ids = batch["item_text_ids"].to(self.device)
-                attention_mask = batch["item_text_masks"].to(self.device)
-                start = time()
-                pred = model.generate(
-                    input_ids=input_ids, attention_mask=attention_mask, max_length=max_length,
-                    prefix_allowed_tokens_fn=fn, num_beams=K, num_return_sequences=K, output_scores=True,
-                    return_dict_in_generate=True, length_penalty=self.length_penalty,
-                )
-                total_time += time() - start  # generate() alone, as single_runner_gram.py:640-652 times it (it returns synchronised)
-                scores = pred["sequences_scores"].detach().cpu().numpy()
-                gold = self._decode(batch["target_ids"])
-                gen = self._decode(pred["sequences"])
-                rel = evaluate.rel_results(gen, gold, scores, K)
-                ranks.append(evaluate.hit_ranks(rel))
-                user_ids += list(batch.get("user_ids", [None] * len(gold)))
-                for b in range(len(gold)):
-                    rows_out.append((gold[b], gen[b * K:(b + 1) * K], scores[b * K:(b + 1) * K]))
-                    if len(examples) < 10:
-                        examples.append(f"[GT] {gold[b]} || [top-1] {gen[b * K]}")
-        ranks = np.concatenate(ranks) if ranks else np.zeros(0, dtype=np.int16)
-        return ranks, total_time, examples, user_ids, rows_out
+        on_device_items = hasattr(model, "sequence_items")
+        # one decode of the candidate list; sid = id of a distinct decoded string (first item that decodes to it)
+        cand_str = self._decode_rows(encoded)
+        str2sid = {}
+        for i, s in enumerate(cand_str):
+            str2sid.setdefault(s, i)
+        cand_sid = np.fromiter((str2sid[s] for s in cand_str), dtype=np.int64, count=len(cand_str))
+        other_sid = {}  # strings that are not candidates (fillers, unknown golds): ids below zero
+
+        def sid_of(s):
+            r = str2sid.get(s)
+            if r is None:
+                r = other_sid.setdefault(s, -2 - len(other_sid))
+            return r
+
+        collator = getattr(testloader, "collate_fn", None)
+        n_slots = int(_arg(self.args, "max_his", 20)) + 1
+        L = int(getattr(collator, "item_prompt_max_len", 0) or _arg(self.args, "item_prompt_max_len", 128))
+        users_per_call = self._gpu_batch_users(model, n_slots, L, K, max_length)
+        lap("candidate_strings")
+        logging.info(f"scoring {users_per_call} users per generate() call (--eval_batch_size {_arg(self.args, 'eval_batch_size', 1)} "
+                     f"is the loader's; results do not depend on the batch)")
+
+        batches_q: "queue.Queue" = queue.Queue(maxsize=2)
+        post_q: "queue.Queue" = queue.Queue(maxsize=4)
+        failure = []
+
+        def produce():
+            try:
+                for batch in self._gpu_batches(testloader, users_per_call):
+                    batches_q.put(batch)
+            except BaseException as e:  # surfaced by the consumer
+                failure.append(e)
+            batches_q.put(None)
+
+        out = dict(ranks=[], user_ids=[], gold=[], items=[], scores=[], extra=[])
+
+        def post_one(batch, items, scores, seqs):
+            B = scores.shape[0]
+            gold = self._decode(batch["target_ids"])
+            gold_sid = np.fromiter((sid_of(g) for g in gold), dtype=np.int64, count=B)
+            extra = {}
+            if items is None:  # a model without sequence_items: decode every generated row, like the reference
+                gen = self._decode(seqs)
+                pred_sid = np.fromiter((sid_of(s) for s in gen), dtype=np.int64, count=B * K).reshape(B, K)
+                extra = dict(enumerate(gen))
+                items = np.full((B, K), -1, dtype=np.int32)
+            else:
+                pred_sid = np.where(items >= 0, cand_sid[np.maximum(items, 0)], -1)
+                miss = np.argwhere(items < 0)
+                if len(miss):
+                    strs = self._decode(seqs[miss[:, 0] * K + miss[:, 1]])
+                    for (b, k), s in zip(miss.tolist(), strs):
+                        pred_sid[b, k] = sid_of(s)
+                        extra[b * K + k] = s
+            out["ranks"].append(evaluate.hit_ranks_from_ids(pred_sid, scores, gold_sid))
+            out["user_ids"] += list(batch.get("user_ids", [None] * B))
+            out["gold"] += gold
+            out["items"].append(items)
+            out["scores"].append(scores)
+            out["extra"].append(extra)
+
+        def post():
+            while True:
+                job = post_q.get()
+                if job is None:
+                    return
+                if failure:
+                    continue  # keep draining so that the scoring loop never blocks on a full queue
+                try:
+                    post_one(*job)
+                except BaseException as e:
+                    failure.append(e)
+
+        producer = threading.Thread(target=produce, name="gram-collate", daemon=True)
+        poster = threading.Thread(target=post, name="gram-post", daemon=True)
+        producer.start()
+        poster.start()
+        total_time = 0.0
+        try:
+            with torch.no_grad():
+                while True:
+                    lap("post_handoff")
+                    batch = batches_q.get()
+                    lap("wait_for_collate")
+                    if batch is None or failure:
+                        break
+                    input_ids = batch["item_text_ids"].to(self.device)
+                    attention_mask = batch["item_text_masks"].to(self.device)
+                    start = time()
+                    pred = model.generate(
+                        input_ids=input_ids, attention_mask=attention_mask, max_length=max_length,
+                        prefix_allowed_tokens_fn=fn, num_beams=K, num_return_sequences=K, output_scores=True,
+                        return_dict_in_generate=True, length_penalty=self.length_penalty,
+                    )
+                    lap("h2d_and_generate")
+                    total_time += time() - start  # generate() alone, as single_runner_gram.py:640-652 times it (it returns synchronised)
+                    B = input_ids.shape[0]
+                    seqs = pred["sequences"]
+                    items = model.sequence_items(seqs, fn, encoded).cpu().numpy().reshape(B, K) if on_device_items else None
+                    scores = pred["sequences_scores"].detach().cpu().numpy().reshape(B, K)
+                    need_seqs = items is None or bool((items < 0).any())
+                    post_q.put((batch, items, scores, seqs.detach().cpu() if need_seqs else None))
+        finally:
+            post_q.put(None)
+            poster.join()
+            if producer.is_alive():  # a failure on this side: unblock the producer and let it finish
+                while producer.is_alive():
+                    try:
+                        batches_q.get(timeout=0.05)
+                    except queue.Empty:
+                        pass
+        lap("drain_post")
+        if failure:
+            raise failure[0]
+        ranks = np.concatenate(out["ranks"]) if out["ranks"] else np.zeros(0, dtype=np.int16)
+        rows_out = _PredRows(out["gold"], out["items"], out["scores"], out["extra"], cand_str, K)
+        examples = [f"[GT] {g} || [top-1] {gen[0]}" for g, gen, _ in rows_out.head(10)]
+        self.last_host = dict(users_per_call=users_per_call, phases=phases)
+        return ranks, total_time, examples, out["user_ids"], rows_out
 
     # the reference writes this literal header whatever `metrics` is (single_runner_gram.py:588, distributed :720)
     PRED_HEADER = "idx\tH@5\tH@10\tNDCG@5\tNDCG@10\tgold\tpred\tscores\n"
@@ -202,8 +415,9 @@ class BaseRunner:
         os.makedirs(os.path.dirname(os.path.abspath(fname)), exist_ok=True)
         with open(fname, "w") as f:
             f.write(self.PRED_HEADER)
+            table = evaluate.metric_table(self.metrics, K)
             for uid, r, (gold, gen, sc) in zip(user_ids, ranks, rows_out):
-                per = evaluate.metrics_from_ranks([r], self.metrics, K)
+                per = table[int(r) + 1]
                 f.write("\t".join([str(uid), "\t".join(str(x) for x in per), str(gold), "||".join(map(str, gen)),
                                    "||".join(str(s) for s in sc)]) + "\n")
             if footer is not None:

@@ -133,10 +133,17 @@ class DistributedRunnerGRAM(BaseRunner):
         dev = self.device if dist.get_backend() != "gloo" else torch.device("cpu")
         save = bool(_arg(self.args, "save_predictions", False))
         stamp = self._timestamp(dev) if save and not _arg(self.args, "pred_path", None) else None
-        ranks, total_time, examples, user_ids, rows_out = self._score_loader(testloader)
         world = dist.get_world_size()
         # dataset indices of this rank's users, in scoring order; the sampler fixes the shard width ceil(n / W) for every rank
         sampler = getattr(testloader, "sampler", None)
+        # The all-gather's width is ceil(n / W), known without a collective; a caller-supplied loader whose split gives one rank
+        # more than that (contiguous chunks with a bigger last one, say) would fail only AFTER its whole shard was scored.
+        width = math.ceil(len(testloader.dataset) / world)
+        if sampler is not None and hasattr(sampler, "__len__") and len(sampler) > width:
+            raise ValueError(f"rank {self.rank}: the loader's sampler yields {len(sampler)} users, more than the shard width "
+                             f"ceil({len(testloader.dataset)}/{world}) = {width} of the hit-record all-gather; use ShardSampler "
+                             f"(gram_amd.runner) or any split with at most that many users per rank")
+        ranks, total_time, examples, user_ids, rows_out = self._score_loader(testloader)
         idx = np.asarray(getattr(sampler, "indices", range(len(ranks))), dtype=np.int32)[: len(ranks)]
         n_users = len(testloader.dataset)
         n_total = math.ceil(n_users / world) * world if bool(int(_arg(self.args, "eval_pad_like_reference", 0))) else n_users

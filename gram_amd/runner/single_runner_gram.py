@@ -12,6 +12,8 @@ from .base import BaseRunner, _arg
 class SingleRunnerGRAM(BaseRunner):
     def test_dataset_task(self, testloader, mode="test"):
         logging.info(f"[{mode}] testing {testloader.dataset.dataset} dataset on {testloader.dataset.task} task")
+        from time import time
+        t_start = time()
         ranks, total_time, examples, user_ids, rows_out = self._score_loader(testloader)
         K = self.generate_num
         sums = evaluate.metrics_from_ranks(ranks, self.metrics, K)
@@ -34,6 +36,6 @@ class SingleRunnerGRAM(BaseRunner):
             self._write_preds(fname, user_ids, ranks, rows_out, footer=metrics_res.tolist())
             self.last_pred_file = fname
         self.last_results = dict(metrics=dict(zip(self.metrics, metrics_res.tolist())), sums=sums, total=test_total,
-                                 hit_ranks=ranks, generate_seconds=total_time,
+                                 hit_ranks=ranks, generate_seconds=total_time, score_loader_seconds=time() - t_start,
                                  users_per_sec=test_total / total_time if total_time > 0 else float("nan"))
         return True

@@ -76,5 +76,29 @@ def rel_rows_from_ranks(ranks: Sequence[int], k: int) -> List[List[int]]:
     return rows
 
 
+def metric_table(metrics: Sequence[str], k: int) -> np.ndarray:
+    """float64 [k + 1][len(metrics)]: row r + 1 holds a user's metric values when the gold item sits at position r of its
+    score-sorted top-k (row 0: absent) -- the same floats evaluate.py:38-58 produces for that rel row."""
+    tab = np.zeros((k + 1, len(metrics)), dtype=np.float64)
+    for r in range(-1, k):
+        tab[r + 1] = get_metrics_results(rel_rows_from_ranks([r], k), metrics)
+    return tab
+
+
 def metrics_from_ranks(ranks: Sequence[int], metrics: Sequence[str], k: int) -> np.ndarray:
-    return get_metrics_results(rel_rows_from_ranks(ranks, k), metrics)
+    """Metric SUMS over users from their hit ranks.  Same floats as ``get_metrics_results(rel_rows_from_ranks(ranks, k), metrics)``:
+    per user the table row, added up in user order (np.cumsum is a sequential sum, like the reference's ``+=`` loop)."""
+    ranks = np.asarray(ranks, dtype=np.int64)
+    if ranks.size == 0:
+        return np.zeros(len(metrics), dtype=np.float64)
+    return np.cumsum(metric_table(metrics, k)[ranks + 1], axis=0)[-1]
+
+
+def hit_ranks_from_ids(pred_ids: np.ndarray, scores: np.ndarray, gold_ids: np.ndarray) -> np.ndarray:
+    """Vectorised ``hit_ranks(rel_results(...))`` on integer identities: pred_ids / scores (B, k), gold_ids (B,) where two
+    predictions (or a prediction and the gold) carry the same id exactly when the reference's decoded strings are equal, and a
+    gold that equals no candidate carries an id no prediction has.  Stable descending order by score, as evaluate.py:14-15 sorts."""
+    order = np.argsort(-scores.astype(np.float64), axis=1, kind="stable")
+    rel = np.take_along_axis(pred_ids, order, axis=1) == gold_ids[:, None]
+    first = rel.argmax(axis=1)
+    return np.where(rel.any(axis=1), first, -1).astype(np.int16)

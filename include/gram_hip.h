@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GRAM_ABI_VERSION 5
+#define GRAM_ABI_VERSION 6
 
 #define GRAM_E_ARG (-1)       /* bad shape / unsupported size                           */
 #define GRAM_E_WORKSPACE (-2) /* workspace too small (see gram_workspace_bytes)          */
@@ -301,6 +301,16 @@ int gram_greedy_finalize(const gram_beam_state_t* st_host, int max_length, int64
  * fits), scores f32 [B*nret], out_width[0] = min(max hyp len + 1, max_length). */
 int gram_beam_finalize(const gram_beam_state_t* st_host, int nret, int max_length, int64_t* sequences,
                        float* scores, int32_t* out_width, void* stream);
+
+/* Item index of each returned sequence.  Every hypothesis of a Trie-constrained search is a root-to-leaf path of the candidate Trie,
+ * so what the runner does next per user -- tokenizer.batch_decode of the K generated id rows and a string comparison with the decoded
+ * target (single_runner_gram.py:657-673, evaluate.py:5-22) -- needs only WHICH candidate each row spells: the strings come from one
+ * batch_decode of the candidate list per evaluation.  sequences i64 [rows][T] as gram_beam_finalize / gram_generate wrote them (start
+ * token first, 0-padded); node_item i32 [n_nodes]: candidate index of a leaf node (the first one if several candidates share a
+ * sequence), anything for inner nodes.  out_item i32 [rows]: the index, or -1 when the row is not a candidate sequence followed by
+ * padding (the -inf filler beams HF returns when fewer than nret hypotheses finished): the caller decodes those rows itself. */
+int gram_trie_item_index(const gram_trie_t* trie_host, const int32_t* node_item, const int64_t* sequences, int rows, int T,
+                         int32_t* out_item, void* stream);
 
 /* ---- whole-path entry points ---------------------------------------------------------- */
 typedef struct {

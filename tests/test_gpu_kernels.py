@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from gram_amd import _lib
 from oracle import gram_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -486,6 +487,60 @@ def test_beam_search_real_trie_shapes(G):
     assert err == 0
     assert dseq.tolist() == seqs.tolist()
     assert torch.allclose(dscore, scores, atol=2e-5, rtol=1e-6)
+
+
+@pytest.mark.parametrize("bad,where", [(float("nan"), "allowed"), (float("inf"), "allowed"), (float("inf"), "elsewhere"),
+                                       (-float("nan"), "allowed")])
+def test_nonfinite_row_is_flagged_at_its_source(G, bad, where):
+    """a NaN / +inf that reaches only SOME beams must not vanish in the search (a NaN hypothesis loses every heap
+    comparison, a negative NaN sorts below -inf, a row whose normaliser is +inf turns into -inf candidates): the step that meets it
+    sets the error flag (GRAM_E_NONFINITE), whichever beams are finally returned."""
+    from gram_amd.utils import generation_trie as gt
+    cands = _tries()["uniform"]
+    B, K, V = 2, 4, 128
+    max_length = max(len(c) for c in cands)
+    g = torch.Generator().manual_seed(5)
+    logits = [torch.randn(B * K, V, generator=g) for _ in range(max_length - 1)]
+    flat = gt.FlatTrie(gt.Trie(cands))
+    _, _, err, _ = G.device_beam_search([l.to(G.DEV) for l in logits], flat, B, K, max_length, 1.0)
+    assert err == 0
+    # step 1 (second token), ONE row of user 1: an allowed token (10..13 follow every first piece) or a token outside the Trie
+    logits[1][1 * K + 2, 11 if where == "allowed" else 99] = bad
+    _, dscore, err, _ = G.device_beam_search([l.to(G.DEV) for l in logits], flat, B, K, max_length, 1.0)
+    assert err == 4
+
+
+def test_trie_item_index(G):
+    """gram_trie_item_index against the host walk: every Beauty candidate maps to its own index; rows that are not a candidate
+    followed by padding (a prefix, a candidate with a wrong tail, a start-token-only filler, an out-of-vocabulary id) map to -1."""
+    import os
+    from gram_amd.utils import generation_trie as gt
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tries.npz"))
+    cands = [[int(x) for x in r if x >= 0] for r in z["Beauty_cands"]]
+    cands.append(list(cands[7]))  # a duplicate sequence: the first index wins
+    T = max(len(c) for c in cands)
+    flat = gt.FlatTrie(gt.Trie(cands))
+    dev = torch.device(G.DEV)
+    ctrie, _keep = flat.to_device(dev)
+    node_item = flat.node_items_on(dev, cands)
+    rows = torch.zeros(len(cands) + 5, T, dtype=torch.int64)
+    for i, c in enumerate(cands):
+        rows[i, : len(c)] = torch.tensor(c)
+    n = len(cands)
+    short = min(range(n), key=lambda i: len(cands[i]))
+    rows[n, : len(cands[3]) - 2] = torch.tensor(cands[3][:-2])           # a prefix
+    rows[n + 1, : len(cands[short])] = torch.tensor(cands[short])         # a candidate ...
+    rows[n + 1, len(cands[short])] = 5                                    # ... with something behind its EOS
+    rows[n + 2, 0] = 0                                                    # HF's filler: start token + padding
+    rows[n + 3, : len(cands[4])] = torch.tensor(cands[4])
+    rows[n + 3, 2] = 1 << 40                                              # an id no Trie holds
+    rows[n + 4, : len(cands[9])] = torch.tensor(cands[9])                 # (control: a plain candidate again)
+    out = torch.empty(rows.shape[0], dtype=torch.int32, device=dev)
+    rd = rows.to(dev)
+    _lib.check(G.lib().gram_trie_item_index(C.byref(ctrie), G.p(node_item), G.p(rd), rows.shape[0], T, G.p(out), G.stream()), "item_index")
+    got = out.cpu().tolist()
+    want = list(range(n - 1)) + [7] + [-1, -1, -1, -1, 9]
+    assert got == want
 
 
 @pytest.mark.parametrize("M,N,K", [(100, 256, 128), (2560, 32128, 768), (9000, 32128, 768)])

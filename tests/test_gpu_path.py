@@ -84,7 +84,7 @@ def _encode_device(m, ids, mask, K=2, max_length=6):
     B, N, L = ids.shape
     ws = m._get_workspace(handle, B, N, L, K, max_length)
     d = m.config.d_model
-    pieces = m._PIECES[m._precision]  # two-piece mode: the fused encoder states come back interleaved, [B*N*L][2 d]
+    pieces = m._PIECES[m.precision]  # two-piece mode: the fused encoder states come back interleaved, [B*N*L][2 d]
     assert pieces == 2
     enc = torch.empty(B * N * L, 2 * d, dtype=_L.piece_dtype(), device=DEV)
     idd = ids.to(DEV).contiguous()

@@ -63,6 +63,48 @@ def test_single_runner_test_and_validate_from_checkpoint(tmp_path):
     assert runner.last_results["total"] == len(runner.validloaders[0].dataset) == 12
 
 
+def test_rebatched_runner_equals_one_user_per_call(tmp_path):
+    """The drop-in at the reference's default flag (--eval_batch_size 1): the runner scores many users per generate() call and
+    takes item indices from the device; the result -- hit ranks, sums, the whole preds TSV -- is that of one user per call with
+    every generated row decoded on the host (a user's scores do not depend on the batch it is scored in, bit for bit)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gram_amd
+    from gram_amd.runner import get_runner
+    ckpt = str(tmp_path / "model_rec_best.pt")
+    _checkpoint(ckpt)
+    res = []
+    for tag, kw in (("rebatched", dict(eval_batch_size=1)), ("one_by_one", dict(eval_batch_size=1, eval_gpu_batch=1)),
+                    ("sevens", dict(eval_batch_size=4, eval_gpu_batch=7))):
+        pred = str(tmp_path / f"{tag}.tsv")
+        model = gram_amd.create_model("gram", _cfg()).to(DEV)
+        runner = get_runner("single", model, None, PieceTokenizer(), None, None, None, DEV,
+                            fixture_args(save_predictions=True, pred_path=pred, passage_cache=int(tag != "one_by_one"), **kw))
+        if tag == "one_by_one":
+            runner._generate_model = lambda m=model: _NoItems(m)
+        runner.test(ckpt)
+        res.append((runner.last_results, open(pred).read(), runner.last_host["users_per_call"]))
+    (a, ta, ca), (b, tb, cb), (c, tc, cc) = res
+    assert ca >= 12 and cb == 1 and cc == 7
+    assert a["total"] == b["total"] == c["total"] == 12
+    assert a["hit_ranks"].tolist() == b["hit_ranks"].tolist() == c["hit_ranks"].tolist()
+    assert np.array_equal(a["sums"], b["sums"]) and np.array_equal(a["sums"], c["sums"])
+    assert ta == tb == tc
+
+
+class _NoItems:
+    """A model view without `sequence_items`: the runner then decodes every generated row, like the reference."""
+
+    def __init__(self, m):
+        self._m = m
+
+    def generate(self, *a, **kw):
+        return self._m.generate(*a, **kw)
+
+    def cache_passages(self, *a, **kw):
+        return self._m.cache_passages(*a, **kw)
+
+
 def _worker(rank, world, rdzv, ckpt, pred, q):
     import gram_amd
     from gram_amd.runner import get_runner

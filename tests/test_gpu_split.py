@@ -250,7 +250,7 @@ def test_split_generate_vs_oracle(G, name, B, N, L, K):
     m.load_state_dict(sd)
     m = m.to(G.DEV).eval()
     m.set_precision(m.default_precision())
-    assert m._PIECES[m._precision] == 2
+    assert m._PIECES[m.precision] == 2
     g = torch.Generator().manual_seed(3)
     V = min(oc.vocab_size, 32100)
     ids = torch.randint(2, V, (B, N, L), generator=g)
@@ -273,7 +273,7 @@ def test_split_generate_vs_oracle(G, name, B, N, L, K):
     rs, ds = ref["sequences_scores"], out["sequences_scores"].cpu()
     rq, dq = ref["sequences"], out["sequences"].cpu()
     dev = float((rs - ds).abs().max())
-    print(f"\n[split generate] {m._precision} {name}: max |score diff| = {dev:.2e}; sequences equal: {bool(rq.shape == dq.shape and torch.equal(rq, dq))}")
+    print(f"\n[split generate] {m.precision} {name}: max |score diff| = {dev:.2e}; sequences equal: {bool(rq.shape == dq.shape and torch.equal(rq, dq))}")
     if rq.shape == dq.shape and torch.equal(rq, dq):
         assert dev < tol_
     else:  # a reordering is only acceptable between oracle scores closer than the tolerance
