@@ -473,6 +473,7 @@ def main():
                     extras["users_per_s_other_modes"][mode] = f"failed at B={Bm}: {str(ex)[:60]}"
         model.set_precision(args.precision)
         model._workspace = None
+        torch.cuda.empty_cache()  # (before anything small is carved out of the freed block and pins it)
         # (4) SURVEY.md §8(d)'s second metric: end-to-end users/s of the DROP-IN RUNNER -- get_runner("single").test() as
         # main_generative_gram.py:107-127 calls it, with the reference's default --eval_batch_size 1 -- on a synthetic dataset
         # directory of Beauty's size (tools/synth_dataset.py: the real 12 101-item Trie, 22 363 users, N = 3 passages of 128 tokens)

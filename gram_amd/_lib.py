@@ -124,6 +124,7 @@ SIGNATURES = {
     "gram_model_create": (vp, [C.POINTER(ModelDesc)]),
     "gram_model_destroy": (None, [vp]),
     "gram_workspace_bytes": (i64, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gram_workspace_encoder_x_offset": (i64, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gram_encode_fused": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, C.c_int, vp, vp]),
     "gram_decode_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
     "gram_prof_pp_clock": (C.c_int, [C.POINTER(C.c_double), C.c_int]),

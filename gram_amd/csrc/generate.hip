@@ -498,6 +498,12 @@ extern "C" int64_t gram_workspace_bytes(const gram_model_t* m, int B, int N, int
   return carve(m, nullptr, B, N, L, K, max_length).bytes;
 }
 
+extern "C" int64_t gram_workspace_encoder_x_offset(const gram_model_t* m, int B, int N, int L, int K, int max_length) {
+  if (check_shapes(m, B, N, L, K, max_length)) return GRAM_E_ARG;
+  const Workspace w = carve(m, (void*)256, B, N, L, K, max_length);  // (any non-null base: only the offset is wanted)
+  return (int64_t)((const char*)w.x - (const char*)256);
+}
+
 extern "C" int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L,
                                  void* workspace, int64_t workspace_bytes, int K, int max_length, void* enc_out_bf16,
                                  void* stream) {

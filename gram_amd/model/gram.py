@@ -407,6 +407,8 @@ class GRAM(nn.Module):
         dev = self._device()
         if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:
             self._workspace = None
+            torch.cuda.empty_cache()  # hand the old workspace (and whatever else the caching allocator holds unused) back first:
+            #                           the new one is most of the HBM, and the allocator does not always manage that by itself
             self._workspace = torch.empty(int(need), dtype=torch.uint8, device=dev)
         return self._workspace
 
@@ -418,6 +420,7 @@ class GRAM(nn.Module):
         lib = _lib.load()
         dev = self._device()
         Lp = (int(L) + 31) // 32 * 32
+        torch.cuda.empty_cache()  # unused blocks of PyTorch's caching allocator go back to the driver first (once per evaluation)
         free, _total = torch.cuda.mem_get_info(dev)
         if self._workspace is not None and self._workspace.device == dev:
             free += self._workspace.numel()
@@ -438,7 +441,9 @@ class GRAM(nn.Module):
     def _closure_trie(fn: Callable):
         for cell in getattr(fn, "__closure__", None) or ():
             obj = cell.cell_contents
-            if hasattr(obj, "trie_dict") and hasattr(obj, "get"):
+            if isinstance(obj, Trie):  # (checked first: reading `trie_dict` of a gram_amd Trie builds its nested dict)
+                return obj
+            if hasattr(obj, "trie_dict") and hasattr(obj, "get"):  # the reference's own utils.generation_trie.Trie
                 return obj
         return None
 
@@ -474,6 +479,44 @@ class GRAM(nn.Module):
             GRAM._KEY_MULT[canon.device] = mult
         return ((canon.to(torch.int64) + 1) * mult).sum(dim=1)
 
+    # The passage cache: x f32 [capacity][128][d] (the encoder's residual stream before the final norm), canon i32 [capacity][128]
+    # (the tokens: the identity of a passage), n rows in use, keys (sorted) / perm over the rows in use.
+    def _pcache_rows(self, n_new: int):
+        """Make room for n_new more passages; returns (cache dict, first new row).  The buffers grow geometrically (a dataset's item
+        prompts arrive over several batches; `reserve_passage_cache` sizes them once)."""
+        dev, d = self._device(), self.config.d_model
+        pc = self._pcache
+        used = 0 if pc is None else pc["n"]
+        cap = 0 if pc is None else pc["x"].shape[0]
+        if used + n_new > cap:
+            new_cap = max(used + n_new, 2 * cap, int(getattr(self, "_pcache_reserve", 0)))
+            x = torch.empty(new_cap, self._CACHE_L, d, dtype=torch.float32, device=dev)
+            canon = torch.full((new_cap, self._CACHE_L), -1, dtype=torch.int32, device=dev)
+            if used:
+                x[:used].copy_(pc["x"][:used])
+                canon[:used].copy_(pc["canon"][:used])
+            pc = dict(x=x, canon=canon, n=used, keys=None if pc is None else pc["keys"], perm=None if pc is None else pc["perm"])
+            self._pcache = pc
+        return pc, used
+
+    def _pcache_commit(self, pc, n_total: int) -> None:
+        keys = self._passage_keys(pc["canon"][:n_total])
+        pc["keys"], pc["perm"] = torch.sort(keys, stable=True)
+        pc["n"] = n_total
+
+    def reserve_passage_cache(self, n_passages: int) -> None:
+        """Capacity hint: the number of distinct passages that will be cached (a dataset's item count)."""
+        self._pcache_reserve = int(n_passages)
+
+    def set_passage_harvest(self, on: bool = True, first_slot: int = 1) -> None:
+        """With harvesting on, every passage a ``generate`` call had to encode in a slot >= first_slot joins the passage cache when
+        the call returns -- its residual-stream rows are still in the workspace (gram_workspace_encoder_x_offset), nothing is
+        encoded twice -- so an evaluation needs no separate cache-fill pass: a batch pays for the item prompts it is the first to
+        see and the later ones find them.  Slot 0 is the user's own prompt (test_dataset_gram.py:203-210), never seen again.
+        Results do not change (the cache is result-neutral bit for bit)."""
+        self._harvest = bool(on)
+        self._harvest_first_slot = int(first_slot)
+
     @torch.no_grad()
     def cache_passages(self, input_ids, attention_mask, chunk: int = 1024) -> int:
         """Pre-encode user-independent passages.
@@ -495,38 +538,37 @@ class GRAM(nn.Module):
             raise ValueError(f"passages must be (P, L <= {self._CACHE_L}) ids with a mask of the same shape")
         keep = mask.any(dim=1)
         canon = self._canonical(ids[keep], mask[keep])
-        keys = self._passage_keys(canon)
-        # drop duplicates inside the call and passages already cached
-        order = torch.argsort(keys, stable=True)
-        first = torch.ones_like(keys, dtype=torch.bool)
-        first[order[1:]] = keys[order[1:]] != keys[order[:-1]]
-        if self._pcache is not None:
-            first &= self._lookup(canon, keys)[0].logical_not()
-        canon = canon[first]
-        if canon.shape[0] == 0:
-            return 0 if self._pcache is None else int(self._pcache["canon"].shape[0])
-        d = self.config.d_model
+        canon = canon[self._first_unseen(canon)]
+        n_new = int(canon.shape[0])
+        if n_new == 0:
+            return 0 if self._pcache is None else int(self._pcache["n"])
         full_ids = canon.clamp(min=0).to(torch.int64).contiguous()
         full_mask = canon.ge(0).view(torch.uint8).contiguous()
-        x = torch.empty(canon.shape[0], self._CACHE_L, d, dtype=torch.float32, device=dev)
+        pc, base = self._pcache_rows(n_new)
+        pc["canon"][base:base + n_new] = canon
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            for lo in range(0, canon.shape[0], chunk):
-                n = min(chunk, canon.shape[0] - lo)
+            for lo in range(0, n_new, chunk):
+                n = min(chunk, n_new - lo)
                 ws = self._get_workspace(handle, n, 1, self._CACHE_L, 1, 2)
                 _lib.check(lib.gram_encode_passages(handle, full_ids[lo:lo + n].data_ptr(), full_mask[lo:lo + n].data_ptr(), n,
-                                                    self._CACHE_L, ws.data_ptr(), ws.numel(), x[lo:lo + n].data_ptr(), stream),
-                           "gram_encode_passages")
-        if self._pcache is not None:
-            x = torch.cat([self._pcache["x"], x], 0)
-            canon = torch.cat([self._pcache["canon"], canon], 0)
-        keys = self._passage_keys(canon)
-        skeys, perm = torch.sort(keys, stable=True)
-        self._pcache = dict(x=x.contiguous(), canon=canon.contiguous(), keys=skeys, perm=perm)
-        return int(canon.shape[0])
+                                                    self._CACHE_L, ws.data_ptr(), ws.numel(), pc["x"][base + lo:base + lo + n].data_ptr(),
+                                                    stream), "gram_encode_passages")
+        self._pcache_commit(pc, base + n_new)
+        return base + n_new
 
     def clear_passage_cache(self) -> None:
         self._pcache = None
+
+    def _first_unseen(self, canon: torch.Tensor) -> torch.Tensor:
+        """bool [P]: the first occurrence of every passage of `canon` that the cache does not hold yet."""
+        keys = self._passage_keys(canon)
+        order = torch.argsort(keys, stable=True)
+        first = torch.ones_like(keys, dtype=torch.bool)
+        first[order[1:]] = keys[order[1:]] != keys[order[:-1]]
+        if self._pcache is not None and self._pcache["n"] > 0:
+            first &= self._lookup(canon, keys)[0].logical_not()
+        return first
 
     def _lookup(self, canon: torch.Tensor, keys: torch.Tensor):
         pc = self._pcache
@@ -536,17 +578,24 @@ class GRAM(nn.Module):
         return hit, slot
 
     def _plan_encoder(self, ids, mask, B, N, Lp):
-        """gram_compaction_t for this batch, or None when the encoder simply runs on all B*N passages.
+        """gram_compaction_t for this batch as (struct, keep-alive list, tensors), or None when the encoder simply runs on all B*N passages."""
+        return self._plan(ids, mask, B, N, Lp)[0]
+
+    def _plan(self, ids, mask, B, N, Lp):
+        """(gram_compaction_t for this batch -- or None when the encoder simply runs on all B*N passages --, harvest plan or None).
 
         Ragged batches: the Collator pads every user to the batch's largest passage count with fully masked passages
         (Collator.py:410-436); the encoder skips them.  Passages found in the passage cache skip it too.  One small
-        D2H sync for the counts; the gathers are input plumbing.  GRAM_COMPACT=0 disables both."""
-        if os.environ.get("GRAM_COMPACT", "1") == "0" or (N == 1 and self._pcache is None):
-            return None
+        D2H sync for the counts; the gathers are input plumbing.  GRAM_COMPACT=0 disables both.
+        Harvest plan (set_passage_harvest): (compact rows of the passages to add to the cache after the call, their tokens)."""
+        harvest = bool(getattr(self, "_harvest", False)) and N > int(getattr(self, "_harvest_first_slot", 1))
+        have = self._pcache is not None and self._pcache["n"] > 0
+        if os.environ.get("GRAM_COMPACT", "1") == "0" or (N == 1 and not have):
+            return None, None
         rows_ids, rows_mask = ids.view(B * N, Lp), mask.view(B * N, Lp)
         active = rows_mask.ne(0).any(dim=1)
-        if self._pcache is not None:
-            canon = self._canonical(rows_ids, rows_mask)
+        canon = self._canonical(rows_ids, rows_mask) if (have or harvest) else None
+        if have:
             hit, slot = self._lookup(canon, self._passage_keys(canon))
             hit &= active
         else:
@@ -555,8 +604,18 @@ class GRAM(nn.Module):
         n_miss, n_hit, users = torch.stack([miss.sum(), hit.sum(), active.view(B, N).any(dim=1).sum()]).tolist()
         if users < B:
             raise ValueError("every user needs at least one passage with a valid token")
+        plan = None
+        if harvest and n_miss:
+            # misses in slots >= first_slot, one per distinct passage; compact row of flat passage f = its rank among the misses
+            slot_ok = (torch.arange(B * N, device=ids.device) % N) >= self._harvest_first_slot
+            cand = (miss & slot_ok).nonzero().squeeze(1)
+            if cand.numel():
+                c_canon = canon.index_select(0, cand)
+                cand = cand[self._first_unseen(c_canon)]
+                rank = torch.cumsum(miss.to(torch.int64), 0) - 1
+                plan = (rank.index_select(0, cand), canon.index_select(0, cand))
         if n_hit == 0 and n_miss == B * N:
-            return None
+            return None, plan
         midx, hidx = miss.nonzero().squeeze(1), hit.nonzero().squeeze(1)
         c_ids = rows_ids.index_select(0, midx).contiguous()
         c_mask = rows_mask.index_select(0, midx).contiguous()
@@ -570,7 +629,26 @@ class GRAM(nn.Module):
             comp.n_cached, comp.cache_L = n_hit, self._CACHE_L
             comp.cache_x, comp.cache_slot = self._pcache["x"].data_ptr(), slots.data_ptr()
             tens.update(cache_slot=slots, cache_x=self._pcache["x"], n_cached=n_hit, cache_L=self._CACHE_L)
-        return comp, keep, tens
+        return (comp, keep, tens), plan
+
+    def _harvest_from_workspace(self, plan, ws, handle, B, N, Lp, K, max_length) -> None:
+        """Add the planned passages to the cache from the residual stream the generate() call left in the workspace."""
+        rows, canon = plan
+        n_new = int(rows.numel())
+        if n_new == 0:
+            return
+        d = self.config.d_model
+        off = _lib.load().gram_workspace_encoder_x_offset(handle, B, N, Lp, K, max_length)
+        if off < 0:
+            raise _lib.GramHipError("gram_workspace_encoder_x_offset rejected the shape")
+        wx = ws[off: off + B * N * Lp * d * 4].view(torch.float32).view(B * N, Lp, d)
+        pc, base = self._pcache_rows(n_new)
+        dst = pc["x"][base:base + n_new]
+        torch.index_select(wx, 0, rows, out=dst[:, :Lp])
+        if Lp < self._CACHE_L:
+            dst[:, Lp:].zero_()  # positions past the batch's L are padding for these passages (gram_compaction_t.cache_L semantics)
+        pc["canon"][base:base + n_new] = canon
+        self._pcache_commit(pc, base + n_new)
 
     # ------------------------------------------------------------------ the hot path
     @torch.no_grad()
@@ -616,7 +694,7 @@ class GRAM(nn.Module):
                 raise NotImplementedError("greedy search needs the Trie closure form of prefix_allowed_tokens_fn")
             return self._generate_with_callback(ids, mask, B, N, Lp, K, nret, int(max_length), float(length_penalty),
                                                 prefix_allowed_tokens_fn, return_dict_in_generate)
-        comp = self._plan_encoder(ids, mask, B, N, Lp)
+        comp, harvest_plan = self._plan(ids, mask, B, N, Lp)
         flat = self._flat_trie(prefix_allowed_tokens_fn)
         _ctrie, (t_off, t_tok, t_node) = flat.to_device(dev)
         ws = self._get_workspace(handle, B, N, Lp, K, int(max_length))
@@ -629,6 +707,8 @@ class GRAM(nn.Module):
             ids, mask, int(handle), ws, t_off, t_tok, t_node, int(flat.max_fanout), int(flat.min_seq_len), K, nret, int(max_length),
             float(length_penalty), ct["comp_map"], ct["comp_ids"], ct["comp_mask"], ct["cache_slot"], ct["cache_x"],
             int(ct["n_cached"]), int(ct["cache_L"]))
+        if harvest_plan is not None:
+            self._harvest_from_workspace(harvest_plan, ws, handle, B, N, Lp, K, int(max_length))
         seqs = seqs[:, : int(width[0])]
         scores = scores if K > 1 else None  # num_beams == 1 is HF's greedy_search: it has no sequences_scores
         if not return_dict_in_generate:

@@ -147,15 +147,24 @@ class BaseRunner:
         return self.model_rec.module if hasattr(self.model_rec, "module") else self.model_rec
 
     def _warm_passage_cache(self, testloader, chunk: int = 2048) -> int:
-        """Register the dataset's item prompts with the model's passage cache: every user's passages
-        1..h are `item2input[item]` texts (test_dataset_gram.py:115-123,203-210), the same for all users, so their
-        encoder states are computed once per eval instead of once per occurrence.  Needs a dataset exposing
-        `item2input` and a collate_fn with `encode_passages` (gram_amd.processor.CollatorGRAM); `--passage_cache 0`
-        turns it off.  Results do not change (bit-identical, tests/test_gpu_configs.py)."""
-        item2input = getattr(testloader.dataset, "item2input", None)
-        encode = getattr(getattr(testloader, "collate_fn", None), "encode_passages", None)
+        """The passage cache of an evaluation: every user's passages 1..h are `item2input[item]` texts
+        (test_dataset_gram.py:115-123,203-210), the same for all users, so their encoder states are computed once per eval
+        instead of once per occurrence.  `--passage_cache 1` (default): the model HARVESTS them -- an item prompt joins the cache
+        when the first batch that contains it has been scored (GRAM.set_passage_harvest), so nothing runs before the first
+        generate() and items no user has in its history are never encoded.  `--passage_cache 2`: all of `dataset.item2input` is
+        encoded up front (needs a collate_fn with `encode_passages`, gram_amd.processor.CollatorGRAM).  `--passage_cache 0`: off.
+        Results do not change (bit-identical, tests/test_gpu_configs.py)."""
+        mode = int(_arg(self.args, "passage_cache", 1))
         model = self._generate_model()
-        if not item2input or encode is None or not hasattr(model, "cache_passages") or not int(_arg(self.args, "passage_cache", 1)):
+        if hasattr(model, "set_passage_harvest"):
+            model.set_passage_harvest(mode == 1)
+        item2input = getattr(testloader.dataset, "item2input", None)
+        if not mode or not item2input or not hasattr(model, "cache_passages"):
+            return 0
+        if hasattr(model, "reserve_passage_cache"):
+            model.reserve_passage_cache(len(set(item2input.values())))
+        encode = getattr(getattr(testloader, "collate_fn", None), "encode_passages", None)
+        if mode != 2 or encode is None:
             return 0
         texts = sorted(set(item2input.values()))
         start, n = time(), 0
@@ -211,10 +220,12 @@ class BaseRunner:
         if bs is not None and collate is not None and hasattr(data, "__getitem__") and getattr(testloader, "num_workers", 0) == 0 \
                 and not isinstance(data, torch.utils.data.IterableDataset):
             pending = []
+            want = max(1, users_per_call // 4)  # a short first batch: the GPU starts while the first full batch is being collated
             for idx in bs:
                 pending.extend(idx)
-                while len(pending) >= users_per_call:
-                    take, pending = pending[:users_per_call], pending[users_per_call:]
+                while len(pending) >= want:
+                    take, pending = pending[:want], pending[want:]
+                    want = users_per_call
                     yield collate([data[i] for i in take])
             if pending:
                 yield collate([data[i] for i in pending])

@@ -15,25 +15,52 @@ import numpy as np
 
 
 class Trie:
+    """The nested dict is built LAZILY: sequences are remembered as they are added and inserted into ``trie_dict`` on its first
+    access.  ``GRAM.generate`` never needs the dict -- :class:`FlatTrie` is built straight from the sequences -- so an evaluation
+    over 12 101 candidates does not pay for 100 k Python dict inserts; anything that reads ``trie_dict`` / ``get`` / iterates (the
+    reference's own uses) sees exactly the dict the reference builds."""
+
     def __init__(self, sequences: Optional[Iterable[Sequence[int]]] = None):
-        self.trie_dict: Dict[int, dict] = {}
+        self._dict: Dict[int, dict] = {}
+        self._pending: List[List[int]] = []   # added, not yet in the dict
+        self._sequences: Optional[List[List[int]]] = []  # every sequence added so far; None once the dict may have other sources
         self.len = 0
         self.append_trie = None
         self.bos_token_id = None
         for seq in sequences or ():
             self.add(seq)
 
+    @property
+    def trie_dict(self) -> Dict[int, dict]:
+        if self._pending:
+            pending, self._pending = self._pending, []
+            for seq in pending:
+                node = self._dict
+                for tok in seq:
+                    nxt = node.get(tok)
+                    if nxt is None:
+                        nxt = node[tok] = {}
+                    node = nxt
+        self._sequences = None  # the caller holds the dict now and may change it: the sequence list is no longer authoritative
+        return self._dict
+
+    @trie_dict.setter
+    def trie_dict(self, value: Dict[int, dict]) -> None:
+        self._dict, self._pending, self._sequences = value, [], None
+
+    def sequences(self) -> Optional[List[List[int]]]:
+        """Every sequence added, in order -- or None when the tree may hold anything else (dict handed out or assigned)."""
+        return self._sequences
+
     def append(self, trie: "Trie", bos_token_id: int) -> None:
         self.append_trie = trie
         self.bos_token_id = bos_token_id
 
     def add(self, sequence: Sequence[int]) -> None:
-        node = self.trie_dict
-        for tok in sequence:
-            nxt = node.get(tok)
-            if nxt is None:
-                nxt = node[tok] = {}
-            node = nxt
+        seq = [int(t) for t in sequence]
+        self._pending.append(seq)
+        if self._sequences is not None:
+            self._sequences.append(seq)
         self.len += 1
 
     def get(self, prefix_sequence: Sequence[int]) -> List[int]:
@@ -106,6 +133,13 @@ class FlatTrie:
     def __init__(self, trie: Trie):
         if trie.append_trie is not None:
             raise ValueError("FlatTrie: append_trie is not supported (never set by the GRAM runners)")
+        self._device = {}
+        self._node_item = None
+        seqs = trie.sequences() if isinstance(trie, Trie) else None
+        if seqs:
+            self._from_sequences(seqs)
+            self.n_sequences = len(trie)
+            return
         off, toks, nodes = [0], [], []
         queue = [trie.trie_dict]
         depth = [0]
@@ -131,8 +165,55 @@ class FlatTrie:
         fan = np.diff(self.child_off)
         self.max_fanout = int(fan.max()) if len(fan) else 0
         self.n_sequences = len(trie)
-        self._device = {}
-        self._node_item = None  # (candidate list id, np.int32 [n_nodes]), see node_items()
+
+    def _from_sequences(self, seqs: Sequence[Sequence[int]]) -> None:
+        """The same CSR (same breadth-first numbering, children sorted by token) without the nested dict: sort the sequences
+        lexicographically; the nodes of depth p are the distinct length-p prefixes in that order."""
+        n = len(seqs)
+        lens = np.fromiter((len(q) for q in seqs), dtype=np.int64, count=n)
+        width = int(lens.max()) if n else 0
+        toks = np.full((n, max(width, 1)), -1, dtype=np.int64)
+        for i, q in enumerate(seqs):
+            toks[i, : len(q)] = q
+        if n and int(toks[toks >= 0].min(initial=0)) < 0:
+            raise ValueError("token ids must be >= 0")
+        order = np.lexsort(toks.T[::-1]) if n else np.zeros(0, dtype=np.int64)
+        toks, lens = toks[order], lens[order]
+        node = np.zeros(n, dtype=np.int64)     # node of each sequence's prefix at the current depth
+        n_nodes, tok_parts, node_parts, parent_parts, depth_parts = 1, [], [], [], [np.zeros(1, dtype=np.int64)]
+        same = np.ones(n, dtype=bool)          # same[i]: row i has the same prefix (at this depth) as the previous LIVE row
+        for p in range(width):
+            live = np.nonzero(lens > p)[0]
+            if live.size == 0:
+                break
+            sub = toks[live, : p + 1]
+            new = np.ones(live.size, dtype=bool)
+            new[1:] = (sub[1:] != sub[:-1]).any(axis=1)
+            ids = n_nodes + np.cumsum(new) - 1
+            first = live[new]
+            tok_parts.append(toks[first, p])
+            parent_parts.append(node[first])
+            node_parts.append(ids[new])
+            depth_parts.append(np.full(int(new.sum()), p + 1, dtype=np.int64))
+            node[live] = ids
+            n_nodes += int(new.sum())
+        parent = np.concatenate(parent_parts) if parent_parts else np.zeros(0, dtype=np.int64)
+        self.child_tok = (np.concatenate(tok_parts) if tok_parts else np.zeros(0, dtype=np.int64)).astype(np.int32)
+        self.child_node = (np.concatenate(node_parts) if node_parts else np.zeros(0, dtype=np.int64)).astype(np.int32)
+        self.child_off = np.concatenate([[0], np.cumsum(np.bincount(parent, minlength=n_nodes))]).astype(np.int32)
+        self.n_nodes, self.n_edges = n_nodes, int(self.child_tok.size)
+        fan = np.diff(self.child_off)
+        self.max_fanout = int(fan.max()) if len(fan) else 0
+        depth = np.concatenate(depth_parts)
+        leaves = (fan == 0) & (np.arange(n_nodes) > 0)
+        self.min_seq_len = int(depth[leaves].min()) if leaves.any() else 0
+        # the candidate a leaf completes: the FIRST sequence (original order) that ends there
+        end_leaf = fan[node] == 0
+        item = np.full(n_nodes, -1, dtype=np.int64)
+        idx = np.nonzero(end_leaf)[0]
+        by_orig = idx[np.argsort(order[idx], kind="stable")][::-1]  # descending original index: the smallest is written last
+        item[node[by_orig]] = order[by_orig]
+        self._node_item = (seqs, item.astype(np.int32))
 
     def leaf_of(self, sequence: Sequence[int]) -> int:
         """Node the whole sequence ends on (host walk of the CSR), or -1 if it leaves the tree."""
@@ -150,6 +231,9 @@ class FlatTrie:
         candidate a LEAF node completes -- the first one when several candidates share a sequence -- and -1 elsewhere.  What
         ``gram_trie_item_index`` reads to turn returned sequences into item indices.  Level-wise walk: all candidates advance one
         token per round through the sorted child arrays (vectorised; 12 101 Beauty candidates take milliseconds)."""
+        if self._node_item is not None and (self._node_item[0] is candidates or (
+                len(self._node_item[0]) == len(candidates) and list(map(list, candidates)) == self._node_item[0])):
+            return self._node_item[1]  # (built with the tree, from the very sequences it is being asked about)
         n = len(candidates)
         out = np.full(self.n_nodes, -1, dtype=np.int32)
         if n == 0:

@@ -425,6 +425,12 @@ int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids, const uint
  * gram_workspace_bytes(m, P, 1, L, 1, 2).  Feeds gram_compaction_t.cache_x. */
 int gram_encode_passages(const gram_model_t* m, const int64_t* ids, const uint8_t* mask, int P, int L,
                          void* workspace, int64_t workspace_bytes, float* x_out, void* stream);
+/* Byte offset, inside a workspace carved for (B, N, L, K, max_length), of the encoder's fp32 residual stream [passages * L][d_model]
+ * (before final_layer_norm) as the last gram_generate[_ex] / gram_encode_fused on that workspace left it: rows [p*L, (p+1)*L) belong to
+ * compact passage p (the order of gram_compaction_t.ids; b*N + n without a compaction).  It is what gram_encode_passages copies out,
+ * so a caller can add the passages a generate() has just encoded to its passage cache (gram_compaction_t.cache_x) without encoding
+ * them a second time.  < 0: GRAM_E_ARG. */
+int64_t gram_workspace_encoder_x_offset(const gram_model_t* m, int B, int N, int L, int K, int max_length);
 /* x[i][l][:] = l < cache_L ? cache_x[slot[i]][l][:] : 0 for i < n, l < L (d % 4 == 0). */
 int gram_gather_passage_x(const float* cache_x, const int32_t* slot, float* x, int n, int L, int cache_L, int d,
                           void* stream);

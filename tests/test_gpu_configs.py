@@ -284,6 +284,59 @@ def test_passage_cache_is_result_neutral(gpu, backbone, N, L, K, precision):
     assert m._pcache is None
 
 
+@pytest.mark.parametrize("precision", [ONE, TWO])
+def test_passage_harvest_is_result_neutral(gpu, precision):
+    """GRAM.set_passage_harvest: the item passages a generate() call had to encode join the cache from the residual stream the call
+    left in the workspace.  Batches scored one after the other -- the first cold, the later ones served more and more from the
+    cache, at another trimmed length, items in other slots, with a compaction and without -- return what a cache-less model returns,
+    bit for bit; user prompts (slot 0) are never kept; nothing is stored twice."""
+    oc, sd, m = _model(gpu, "small", 9)
+    m.set_precision(precision)
+    cands = _trie_cands("Toys")
+    g = torch.Generator().manual_seed(44)
+    pool, K = 9, 8
+    p_ids, p_mask = _realistic_inputs(g, pool, 1, 96)
+    p_ids, p_mask = p_ids[:, 0], p_mask[:, 0]
+    p_mask[:, 60:] = False  # every pool passage fits the shortest batch below
+    p_ids[:, 60:] = 0
+    p_ids[torch.arange(pool), p_mask.sum(1) - 1] = 1
+    batches = []
+    for (B, N, L, all_valid) in ((6, 4, 96, True), (5, 5, 64, False), (7, 3, 96, False)):
+        ids, mask = _realistic_inputs(g, B, N, L)
+        if all_valid:  # no padded passage, nothing cached yet: the first call runs without a compaction
+            mask[:, :, :40] = True
+            ids = torch.where(mask & (ids == 0), torch.full_like(ids, 7), ids)
+        for b in range(B):
+            for n in range(1, N):
+                if mask[b, n].any() and (b + 2 * n) % 5 != 0:
+                    j = int(torch.randint(0, pool, (1,), generator=g))
+                    ids[b, n], mask[b, n] = p_ids[j, :L], p_mask[j, :L]
+        batches.append((ids, mask))
+    m.clear_passage_cache()
+    m.set_passage_harvest(False)
+    plain = [_generate(m, i, k, cands, K) for i, k in batches]
+    m.set_passage_harvest(True)
+    counts = []
+    for (ids, mask), want in zip(batches, plain):
+        m._workspace.fill_(0xFF)
+        got = _generate(m, ids, mask, cands, K)
+        assert torch.equal(got["sequences"], want["sequences"]) and torch.equal(got["sequences_scores"], want["sequences_scores"])
+        counts.append(m._pcache["n"])
+        # the cache holds each distinct item passage (slots >= 1) seen so far exactly once, and no user prompt
+        seen = {tuple(i[b, n][k[b, n]].tolist()) for i, k in batches[: len(counts)] for b in range(i.shape[0]) for n in range(1, i.shape[1])
+                if k[b, n].any()}
+        held = [tuple(t for t in row if t >= 0) for row in m._pcache["canon"][: m._pcache["n"]].cpu().tolist()]
+        assert sorted(held) == sorted(seen)
+    assert counts[0] > 0 and counts == sorted(counts)
+    # a second pass over the same batches: every item passage is a hit, nothing new is added
+    for (ids, mask), want in zip(batches, plain):
+        got = _generate(m, ids, mask, cands, K)
+        assert torch.equal(got["sequences"], want["sequences"]) and torch.equal(got["sequences_scores"], want["sequences_scores"])
+    assert m._pcache["n"] == counts[-1]
+    m.set_passage_harvest(False)
+    m.clear_passage_cache()
+
+
 def _rand_cands(seed, n_items, lo, hi, alphabet=40):
     import random
     rng = random.Random(seed)
@@ -474,7 +527,7 @@ def test_runner_end_to_end_with_collator(gpu, tmp_path):
     m.clear_passage_cache()
     loader2 = DataLoader(CachedUserSet(users), batch_size=3, shuffle=False, collate_fn=CollatorGRAM(tok, args, mode="test"))
     runner.test_dataset_task(loader2)
-    assert m._pcache is not None and m._pcache["canon"].shape[0] == len(CachedUserSet.item2input)
+    assert m._pcache is not None and m._pcache["n"] == len(CachedUserSet.item2input)  # (harvested batch by batch)
     plan = None
     for batch in loader2:
         plan = m._plan_encoder(batch["item_text_ids"].to(DEV), batch["item_text_masks"].to(DEV).view(torch.uint8),
@@ -506,7 +559,7 @@ def test_dataset_collator_runner_flow_with_passage_cache(gpu, tmp_path, monkeypa
     oc, sd, m = _model(gpu, "small", 13)
     tok = StubTokenizer()
     outs = {}
-    for cache in (1, 0):
+    for cache in (2, 1, 0):  # 2: filled from item2input before scoring; 1 (default): harvested from the batches as they are scored
         args = SimpleNamespace(**a, passage_cache=cache, pred_path=str(tmp_path / f"preds_{cache}.tsv"))
         ds = TestDatasetGRAM(args, "Beauty", "sequential", None, tok, mode="test")
         loader = DataLoader(ds, batch_size=5, shuffle=False, collate_fn=CollatorGRAM(tok, args, mode="test"))
@@ -515,7 +568,8 @@ def test_dataset_collator_runner_flow_with_passage_cache(gpu, tmp_path, monkeypa
         runner.test_dataset_task(loader)
         assert runner.last_results["total"] == len(ds) == 12
         if cache:
-            assert m._pcache["canon"].shape[0] == len(set(ds.item2input.values()))
+            seen = {p for i in range(len(ds)) for p in ds[i]["input"][1:]}
+            assert m._pcache["n"] == (len(set(ds.item2input.values())) if cache == 2 else len(seen))
             for batch in loader:
                 plan = m._plan_encoder(batch["item_text_ids"].to(DEV), batch["item_text_masks"].to(DEV).view(torch.uint8),
                                        *batch["item_text_ids"].shape)
@@ -524,5 +578,5 @@ def test_dataset_collator_runner_flow_with_passage_cache(gpu, tmp_path, monkeypa
         else:
             assert m._pcache is None
         outs[cache] = open(args.pred_path).read()
-    assert outs[1] == outs[0] and outs[1].count("\n") >= 13
+    assert outs[2] == outs[1] == outs[0] and outs[1].count("\n") >= 13
     m.clear_passage_cache()

@@ -88,7 +88,8 @@ def test_gpu_batches_rebatch_the_loader_in_order(per_call):
     got = list(runner._gpu_batches(loader, per_call))
     users = [u for b in got for u in b["user_ids"]]
     assert users == [data[i]["user_id"] for i in range(len(data))]
-    assert all(b["item_text_ids"].shape[0] == per_call for b in got[:-1]) and got[-1]["item_text_ids"].shape[0] <= per_call
+    sizes = [b["item_text_ids"].shape[0] for b in got]
+    assert sizes[0] == min(max(1, per_call // 4), len(data)) and all(z == per_call for z in sizes[1:-1]) and sizes[-1] <= per_call
 
     class Plain:  # a loader that is not a DataLoader: iterated as it is, its batches merged
         def __init__(self, inner):
@@ -99,8 +100,8 @@ def test_gpu_batches_rebatch_the_loader_in_order(per_call):
 
     got2 = list(runner._gpu_batches(Plain(loader), per_call))
     assert [u for b in got2 for u in b["user_ids"]] == users
-    for x, y in zip(got, got2):
-        assert torch.equal(x["item_text_ids"], y["item_text_ids"]) and torch.equal(x["target_ids"], y["target_ids"])
+    whole, whole2 = runner._merge_batches(got), runner._merge_batches(got2)
+    assert torch.equal(whole["item_text_ids"], whole2["item_text_ids"]) and torch.equal(whole["target_ids"], whole2["target_ids"])
 
 
 class FillerStub(StubModel):
@@ -171,3 +172,35 @@ def test_vectorised_metrics_equal_the_loops():
     pred, gold = rng.integers(0, 30, size=(B, Kk)), rng.integers(0, 35, size=B)
     rel = evaluate.rel_results([int(x) for x in pred.reshape(-1)], [int(x) for x in gold], scores.reshape(-1), Kk)
     assert np.array_equal(evaluate.hit_ranks(rel), evaluate.hit_ranks_from_ids(pred, scores, gold))
+
+
+def test_flat_trie_from_sequences_equals_the_nested_dict_walk():
+    """FlatTrie built straight from the added sequences (the lazy Trie never materialises its nested dict on the generate() path) is
+    the CSR the breadth-first walk of the reference-shaped dict gives: random trees with shared prefixes, sequences that are
+    prefixes of others, duplicates; and the lazily built dict is the dict the eager insert gives."""
+    import random
+    rng = random.Random(1)
+    for _ in range(150):
+        seqs = [[0] + [rng.randint(2, 6) for _ in range(rng.randint(0, 4))] + ([1] if rng.random() < 0.8 else [])
+                for _ in range(rng.randint(1, 40))]
+        fast = gt.FlatTrie(gt.Trie(seqs))
+        t = gt.Trie(seqs)
+        nested = t.trie_dict           # handing the dict out makes the sequence list non-authoritative: the walk is used
+        assert t.sequences() is None
+        slow = gt.FlatTrie(t)
+        for name in ("child_off", "child_tok", "child_node"):
+            assert np.array_equal(getattr(fast, name), getattr(slow, name)), (name, seqs)
+        assert (fast.n_nodes, fast.n_edges, fast.max_fanout, fast.min_seq_len) == (slow.n_nodes, slow.n_edges, slow.max_fanout, slow.min_seq_len)
+        leafy = [q for q in seqs if fast.child_off[fast.leaf_of(q) + 1] == fast.child_off[fast.leaf_of(q)]]
+        if leafy:
+            assert np.array_equal(fast.node_items(seqs), slow.node_items(seqs))
+        eager = {}
+        for q in seqs:
+            node = eager
+            for tok in q:
+                node = node.setdefault(tok, {})
+        assert nested == eager and sorted(map(tuple, t)) == sorted({tuple(q) for q in seqs if not any(
+            len(o) > len(q) and o[: len(q)] == q for o in seqs)})
+    t = gt.Trie([[0, 2, 1]])
+    t.add([0, 3, 1])                  # add() after construction is seen by both forms
+    assert gt.FlatTrie(t).n_nodes == 6 and t.get([0]) == [2, 3] and len(t) == 2
