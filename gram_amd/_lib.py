@@ -72,7 +72,8 @@ class Split(C.Structure):
 
 
 class NormFusion(C.Structure):
-    _fields_ = [("xb_out", vp), ("ss_out", vp), ("ss_in", vp), ("nblk_in", i32), ("d", i32), ("eps", f32), ("quarter", i32)]
+    _fields_ = [("xb_out", vp), ("ss_out", vp), ("ss_in", vp), ("nblk_in", i32), ("d", i32), ("eps", f32), ("quarter", i32),
+                ("xs_in", vp), ("xs_out", vp)]
 
 
 class Compaction(C.Structure):
@@ -104,6 +105,8 @@ SIGNATURES = {
     "gram_gemm_bf16": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KVBank), vp]),
     "gram_gemm_bf16_ex": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KVBank), C.POINTER(NormFusion), vp]),
     "gram_row_rscale": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
+    "gram_row_rscale_xs": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, vp]),
+    "gram_embed_ex_xs": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "gram_embed_ex": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "gram_gemm_bf16_lse": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "gram_lse_combine": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),

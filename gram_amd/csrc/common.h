@@ -107,6 +107,28 @@ __device__ __forceinline__ float sumsq4(f32x4 v) {
   return a + b;
 }
 
+// 1/rms of a row from its sum of squares, in ONE spelled-out arithmetic (an explicit fma, then v_rsq_f32): the GEMM kernels that add
+// the partials up themselves and gram_row_rscale must return the same bits (batch invariance), and hipcc decides per call site
+// whether s * inv_d + eps contracts.
+__device__ __forceinline__ float row_rs(float s, float inv_d, float eps) { return rsqrtf(__builtin_fmaf(s, inv_d, eps)); }
+
+// Power-of-two factor of a row's 16-bit copy (gram_norm_fusion_t.xs_out) from the row's sum of squares and the SMALLEST of its
+// 64-column partial sums.  Two IEEE-half pieces hold 22 bits of an element whose scaled magnitude is in [2^-3, 65 504]; below that
+// the low piece goes subnormal (absolute error 2^-25), above it the high piece overflows.  T5 rows carry a few outlier features
+// 10^2 .. 10^4 times the ordinary ones, which dominate the row's rms -- so the factor is set by the ordinary magnitude, estimated
+// from the quietest 64-column block (typ^2 = min block sum / 64): typ * xs lands in [2^-2, 2^-1), the error floor stays 2^-23 of
+// an ordinary element, and an element may be 1.3e5 x typ before it overflows.  A second bound keeps sqrt(sum) * xs <= 2^10 (every
+// element <= 2^10: a row whose blocks all hold outliers, or whose quietest block is nearly empty).  Clamped to [2^-40, 2^20].
+// Spelled once: the embedding, the GEMM kernels and gram_row_rscale_xs must agree bit for bit (batch invariance).
+__device__ __forceinline__ float row_xscale(float sum, float minblk) {
+  const float want = 0.25f * rsqrtf(minblk * (1.0f / 64.0f));  // (+inf for an all-zero block; powers of two: exact products)
+  const float cap = 1024.0f * rsqrtf(sum);
+  const float f = fminf(want, cap);
+  int e = (int)((__float_as_uint(f) >> 23) & 0xffu) - 127;  // floor(log2 f); inf -> 128, 0 / subnormal -> -127: both clamped
+  e = e < -40 ? -40 : (e > 20 ? 20 : e);
+  return __uint_as_float((uint32_t)(e + 127) << 23);
+}
+
 // products of the two-piece mode (gram_hip.h, gram_split_t): (A piece, B piece) pairs, smallest first
 template <int S> struct SplitTab;
 template <> struct SplitTab<1> { static constexpr int NP = 1; static constexpr int A[3] = {0, 0, 0}; static constexpr int B[3] = {0, 0, 0}; };
@@ -119,6 +141,11 @@ __device__ __forceinline__ int inter_off(int n, int pc) { return ((n >> 5) << 6)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {

@@ -82,6 +82,9 @@ struct EpiArgs {
   int ss_nblk, ss_out_nblk;
   int ss_quarter;  // partials per 16 columns ([M][4 * nblk]) instead of per 64: the layout of gemm_stream_kernel (gram_norm_fusion_t.quarter)
   float inv_d, eps;
+  // per-row power-of-two factor of the 16-bit copy of the residual stream (gram_norm_fusion_t.xs_in / xs_out)
+  const float* xs_in;  // producer: xb = pieces(x * xs_in[m]); consumer: the row scale is divided by it
+  float* xs_out;       // consumer: the first n-tile's workgroups write the next producer's factor
   // KV bank
   bf16* bank_k;
   bf16* bank_vt;
@@ -181,23 +184,36 @@ __device__ __forceinline__ void compute_tile(const char* sa, const char* sw, int
 // per tile pair instead of two 8-byte ones -- the store tail of these K=768 GEMMs is issue-bound.
 // consumer side of the folded T5LayerNorm: 1/rms of row m of A from the producer's per-64-column partial sums
 // of squares, added in a fixed order (deterministic)
-__device__ __forceinline__ float row_rscale(const EpiArgs& ep, int m) {
+// mn (optional): the smallest of the row's 64-column partials, sum: their total -- what the next producer's row factor is made of
+// (row_xscale); only meaningful when the partials are added up here (ss_nblk != 0)
+__device__ __forceinline__ float row_rscale(const EpiArgs& ep, int m, float* sum = nullptr, float* mn = nullptr) {
   if (!ep.ss_in) return 1.f;
   if (ep.ss_nblk == 0) return ep.ss_in[m];  // already 1/rms (gram_row_rscale)
   const float2* p = reinterpret_cast<const float2*>(ep.ss_in + (size_t)m * ep.ss_nblk);
-  float s = 0.f;
+  float s = 0.f, lo = INFINITY;
   for (int i = 0; i < ep.ss_nblk / 2; ++i) {
     const float2 v = p[i];
     s += v.x + v.y;
+    lo = fminf(lo, fminf(v.x, v.y));
   }
-  return rsqrtf(s * ep.inv_d + ep.eps);
+  if (sum) *sum = s;
+  if (mn) *mn = lo;
+  return row_rs(s, ep.inv_d, ep.eps);
 }
 
 // The four output rows a lane owns (m = mbase + j*16 + r16).  Called BEFORE a tile's k-loop so that the
 // dependent loads of the partials are hidden behind the main loop instead of stalling the epilogue.
-__device__ __forceinline__ void load_row_scales(const EpiArgs& ep, int mbase, int r16, int M, float (&rs4)[4]) {
+// lead: this wave's tile starts at column 0 -- its lanes g == 0 also publish the next producer's row factors (gram_norm_fusion_t.xs_out)
+__device__ __forceinline__ void load_row_scales(const EpiArgs& ep, int mbase, int r16, int M, float (&rs4)[4], bool lead = false) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) rs4[j] = row_rscale(ep, min(mbase + j * 16 + r16, M - 1)) * ep.out_scale;
+  for (int j = 0; j < 4; ++j) {
+    const int m = min(mbase + j * 16 + r16, M - 1);
+    float sum = 0.f, mn = 0.f;
+    const float r = row_rscale(ep, m, &sum, &mn);
+    // (ss_nblk == 0: ss_in already holds rsqrt(..) / xs, gram_row_rscale_xs; a power of two: the division is exact)
+    rs4[j] = (ep.xs_in && ep.ss_in && ep.ss_nblk != 0 ? r / ep.xs_in[m] : r) * ep.out_scale;
+    if (lead && ep.xs_out && ep.ss_in && ep.ss_nblk != 0 && mbase + j * 16 + r16 < M) ep.xs_out[m] = row_xscale(sum, mn);
+  }
   // pin the values HERE: without this hipcc sinks the dependent loads down to their use in the epilogue
   // (registers are tight), where they stall every tile by ~3 us
   if (ep.ss_in) {
@@ -313,7 +329,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
           const f32x4 nv = *p + v;
           *p = nv;
           if (ep.xb_out) {
-            f32x4 rem = nv;
+            f32x4 rem = ep.xs_in ? nv * ep.xs_in[m] : nv;
             bf16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
             for (int pc = 0; pc < ep.split; ++pc) {
               const uint2 pk = pack_bf16x4(rem);
@@ -403,7 +419,7 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
         *pc = val;
         if constexpr (EPI == GRAM_EPI_F32_ADD) {
           if (ep.xb_out) {
-            f32x4 rem = val;
+            f32x4 rem = ep.xs_in ? val * ep.xs_in[m] : val;
             bf16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
             const int n = n0 + wn * 64 + c * 4;
             for (int pc = 0; pc < ep.split; ++pc) {
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
     epilogue_rows64<EPI>(acc, reinterpret_cast<char*>(&xch[0][0][0]), m0, n0, 0, 0, lane, M, ep);
   } else {
     float rs4[4];
-    load_row_scales(ep, m0, r16, M, rs4);
+    load_row_scales(ep, m0, r16, M, rs4, n0 == 0);
     epilogue<EPI, 4>(acc, m0, n0, 0, 0, r16, g, M, ep, rs4);
   }
 }
@@ -573,9 +589,11 @@ __device__ __forceinline__ void wait_later(int later) {
 
 // 1/rms of row m of A for the streaming kernel: the partials' loads go out together (row_rscale's loop waits for each), the sums
 // are row_rscale's -- pairs of 64-column blocks in order; a block of the quarter layout is (q0 + q1) + (q2 + q3)
-__device__ __forceinline__ float row_rscale_stream(const EpiArgs& ep, int m) {
+__device__ __forceinline__ float row_rscale_stream(const EpiArgs& ep, int m, float& sum, float& mn) {
+  sum = 0.f;
+  mn = 0.f;
   if (ep.ss_nblk == 0) return ep.ss_in[m];  // already 1/rms
-  float s = 0.f;
+  float s = 0.f, lo = INFINITY;
   const int npair = ep.ss_nblk / 2;
   if (ep.ss_quarter) {
     const float4* p = reinterpret_cast<const float4*>(ep.ss_in + (size_t)m * ep.ss_nblk * 4);
@@ -589,6 +607,7 @@ __device__ __forceinline__ float row_rscale_stream(const EpiArgs& ep, int m) {
           const float pa = (v[2 * u].x + v[2 * u].y) + (v[2 * u].z + v[2 * u].w);
           const float pb = (v[2 * u + 1].x + v[2 * u + 1].y) + (v[2 * u + 1].z + v[2 * u + 1].w);
           s += pa + pb;
+          lo = fminf(lo, fminf(pa, pb));
         }
     }
   } else {
@@ -599,10 +618,15 @@ __device__ __forceinline__ float row_rscale_stream(const EpiArgs& ep, int m) {
       for (int u = 0; u < 8; ++u) v[u] = p[min(i0 + u, npair - 1)];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (i0 + u < npair) s += v[u].x + v[u].y;
+        if (i0 + u < npair) {
+          s += v[u].x + v[u].y;
+          lo = fminf(lo, fminf(v[u].x, v[u].y));
+        }
     }
   }
-  return rsqrtf(s * ep.inv_d + ep.eps);
+  sum = s;
+  mn = lo;
+  return row_rs(s, ep.inv_d, ep.eps);
 }
 
 template <int EPI, int MT, bool X3>
@@ -648,7 +672,13 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
 
   float rs = ep.out_scale;
   if constexpr (EPI != GRAM_EPI_F32_ADD) {
-    if (consumer && ep.ss_in) rs = row_rscale_stream(ep, min(m0 + wave * 16 + r16, M - 1)) * ep.out_scale;
+    if (consumer && ep.ss_in) {
+      const int mr = min(m0 + wave * 16 + r16, M - 1);
+      float sum, mn;
+      const float r = row_rscale_stream(ep, mr, sum, mn);
+      rs = (ep.xs_in && ep.ss_nblk != 0 ? r / ep.xs_in[mr] : r) * ep.out_scale;  // (a power of two: exact)
+      if (ep.xs_out && ep.ss_nblk != 0 && ntile == 0 && g == 0 && m0 + wave * 16 + r16 < M) ep.xs_out[mr] = row_xscale(sum, mn);
+    }
     asm volatile("" : "+v"(rs));  // (the partials' loads are waited for here, behind the first DMAs, not in the epilogue)
   }
 
@@ -716,7 +746,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
       val += *pc;
       *pc = val;
       if (ep.xb_out) {
-        f32x4 rem = val;
+        f32x4 rem = ep.xs_in ? val * ep.xs_in[m] : val;
         bf16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
         for (int p = 0; p < ep.split; ++p) {
           const uint2 pk = pack_bf16x4(rem);
@@ -876,7 +906,7 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
     };
     const int npro = min(NST - 1, nkt);
     for (int kt = 0; kt < npro; ++kt) issue();
-    load_row_scales(ep, m0 + wm * 64, r16, M, rs4);  // (waited for behind the first DMAs)
+    load_row_scales(ep, m0 + wm * 64, r16, M, rs4, n0 == 0 && wn == 0);  // (waited for behind the first DMAs)
     int c_slot = 0;
     for (int kt = 0; kt < nkt; ++kt) {
       wait_later<Q>(min(NST - 2, nkt - 1 - kt));
@@ -887,7 +917,7 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
     }
     __syncthreads();  // (the row-contiguous epilogue re-uses the ring as its patches)
   } else {
-  load_row_scales(ep, m0 + wm * 64, r16, M, rs4);
+  load_row_scales(ep, m0 + wm * 64, r16, M, rs4, n0 == 0 && wn == 0);
   if constexpr (NST == 1) {
     for (int kt = 0; kt < nkt; ++kt) {
       dma(kt, 0);
@@ -952,6 +982,7 @@ struct PPOut {
   char* c;          // C + (m_first * ldc + n_first) * esize
   char* xb;         // xb_out likewise (bf16), or nullptr
   float* ss;        // ss_out + m_first * nblk + n_first / 64, or nullptr
+  const float* xs;  // xs_in + m_first: the rows' power-of-two factors of the 16-bit copy (gram_norm_fusion_t), or nullptr
   uint32_t ldc_b;   // ldc * esize
   uint32_t ldx_b;   // ldc * 2
   uint32_t ss_nblk;
@@ -1033,7 +1064,7 @@ __device__ __forceinline__ void pp_store_rows_impl(f32x4 (&acc)[4][8], int j0, c
           *pc = val;
           if constexpr (EPI == GRAM_EPI_F32_ADD) {
             if (o.xb) {
-              *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + c * 8)) = pack_bf16x4(val);
+              *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + c * 8)) = pack_bf16x4(o.xs ? val * o.xs[mr] : val);
               ssq = sumsq4(val);
             }
           }
@@ -1064,9 +1095,13 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     f32x4 res[16];
+    // row factors of the 16-bit copy: lane l holds the factor of the half's row l (ONE coalesced load with the residuals; a pass
+    // fetches its row's by a cross-lane read -- sixteen registers of them per lane spill, the kernel sits at 256 VGPRs)
+    float xsl = 1.f;
     if constexpr (EPI == GRAM_EPI_F32_ADD) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) res[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (o.rows > 0 && o.xs) xsl = o.xs[min(half * 64 + lane, o.rows - 1)];
       if (o.rows > 0) {  // (wave-uniform; a wave whose first row is past M has nothing to load: o.c points past the matrix)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -1099,13 +1134,14 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
           *pc = val;
           if constexpr (EPI == GRAM_EPI_F32_ADD) {
             if (o.xb) {
+              const f32x4 xv = val * __shfl(xsl, p * 16 + it * 4 + (lane >> 4), 64);  // the 16-bit copy carries the row's power-of-two factor
               if (o.split == 2) {
                 // interleaved copy (lanes 0..7 hold block 0 of the wave's 64 columns, lanes 8..15 block 1; a block = piece 0's 64 B, then
                 // piece 1's): lanes c and c ^ 1 swap one piece each, so that the even lane stores 16 B of piece 0 (columns 4c .. 4c + 7)
                 // and the odd lane 16 B of piece 1 -- one 16-B store per lane instead of two 8-B ones (the tile-end store tail is bound by
                 // its instruction count: an 8-B-per-lane store costs as much as a 16-B one)
                 uint2 p0, p1;
-                split2x4(val, p0, p1);
+                split2x4(xv, p0, p1);
                 const bool odd = c & 1;
                 const uint2 send = odd ? p0 : p1;
                 uint2 recv;
@@ -1115,7 +1151,7 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
                 const uint32_t xoff = (uint32_t)((c >> 3) * 128 + (odd ? 64 : 0) + ((c & 6) * 8));
                 *reinterpret_cast<uint4*>(o.xb + ((uint32_t)mr * o.ldx_b + xoff)) = out;
               } else {
-                *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + (uint32_t)(c * 8))) = pack_bf16x4(val);
+                *reinterpret_cast<uint2*>(o.xb + ((uint32_t)mr * o.ldx_b + (uint32_t)(c * 8))) = pack_bf16x4(xv);
               }
               ssq = sumsq4(val);
             }
@@ -1706,6 +1742,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     // (split == 2: xb is interleaved, [M][2 * ldc])
     o.xb = ep.xb_out ? reinterpret_cast<char*>(ep.xb_out) + (mf * ep.ldc + nf) * 2 * ep.split : nullptr;
     o.ss = ep.ss_out ? ep.ss_out + mf * ep.ss_out_nblk + (nf >> 6) : nullptr;
+    o.xs = ep.xs_in && ep.xb_out ? ep.xs_in + mf : nullptr;
     o.ldc_b = ep.ldc * ESZ;
     o.ldx_b = ep.ldc * 2 * ep.split;
     o.ss_nblk = ep.ss_out_nblk;
@@ -2391,6 +2428,7 @@ extern "C" int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M
       ep.ss_out = nf->ss_out;
       ep.ss_quarter = nf->quarter != 0 && nf->ss_out;
       ep.ss_out_nblk = ep.ss_quarter ? N / 16 : N / 64;
+      ep.xs_in = nf->xb_out ? nf->xs_in : nullptr;
     } else if (epilogue == GRAM_EPI_BF16 || epilogue == GRAM_EPI_BF16_RELU) {
       if (nf->ss_in && nf->nblk_in != 0 && (nf->nblk_in < 2 || (nf->nblk_in & 1) || nf->d < 64)) return GRAM_E_ARG;
       ep.ss_in = nf->ss_in;
@@ -2398,6 +2436,9 @@ extern "C" int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M
       ep.ss_quarter = nf->quarter != 0 && nf->ss_in && nf->nblk_in != 0;
       ep.inv_d = 1.0f / (float)nf->d;
       ep.eps = nf->eps;
+      if (nf->xs_out && (nf->xs_out == nf->xs_in || !nf->ss_in || nf->nblk_in == 0)) return GRAM_E_ARG;
+      ep.xs_in = nf->ss_in && nf->nblk_in != 0 ? nf->xs_in : nullptr;
+      ep.xs_out = nf->xs_out;
     } else if (nf->xb_out || nf->ss_out || nf->ss_in) {
       return GRAM_E_ARG;
     }

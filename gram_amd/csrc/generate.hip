@@ -75,6 +75,7 @@ struct Workspace {
   bf16* u;          // [Me][d_ff]
   float* ss;        // [Me][d/64]  folded-norm partial sums of squares
   float* rs;        // [Me]        1/rms per row
+  float* xs[2];     // [Me] x 2    per-row power-of-two factors of the 16-bit copy of x (gram_norm_fusion_t.xs_in / xs_out), ping-pong
   // fused bank
   bf16* bank_k;     // [layers][B][H][S][64]
   bf16* bank_vt;    // [layers][B][H][S/32][64][32]
@@ -87,6 +88,7 @@ struct Workspace {
   bf16* ud;         // [R][d_ff]
   float* ssd;       // [R][d/64]
   float* rsd;       // [R]
+  float* xsd[2];    // [R] x 2
   bf16* kcache;     // [layers][Tmax][R][inner]
   bf16* vcache;
   float* logits;    // [R][V]
@@ -129,6 +131,8 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   w.u = cv.take<bf16>(P * Me * F);
   w.ss = cv.take<float>(ss_floats(Me, d));
   w.rs = cv.take<float>(Me);
+  w.xs[0] = cv.take<float>(Me);
+  w.xs[1] = cv.take<float>(Me);
   w.bank_k = cv.take<bf16>(P * w.ps_bank);
   w.bank_vt = cv.take<bf16>(P * w.ps_bank);
   w.xd = cv.take<float>(R * d);
@@ -139,6 +143,8 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   w.ud = cv.take<bf16>(P * R * F);
   w.ssd = cv.take<float>(ss_floats(R, d));  // (16-column partials for a small-M step: gram_norm_fusion_t.quarter)
   w.rsd = cv.take<float>(R);
+  w.xsd[0] = cv.take<float>(R);
+  w.xsd[1] = cv.take<float>(R);
   w.kcache = cv.take<bf16>(P * w.ps_cache);
   w.vcache = cv.take<bf16>(P * w.ps_cache);
   w.logits = cv.take<float>(R * V);
@@ -234,29 +240,52 @@ int encoder_layers(const gram_model* m, const Workspace& w, const int64_t* ids, 
     // per-row sum-of-squares partials; both are refreshed by every residual GEMM's epilogue
     // few rows (one short user): the streaming GEMM and its 16-column partials (gram_norm_fusion_t.quarter); the embedding writes 64-column ones
     const int quarter = Me <= gram_gemm_stream_max_m() && d % 128 == 0 && inner % 128 == 0 && F % 128 == 0;
-    const gram_norm_fusion_t produce{w.h, w.ss, nullptr, 0, 0, 0.f, quarter};
     // big problems (the ping-pong GEMMs, M >= kPrecomputedRsRows) take 1/rms precomputed per row by one tiny kernel per
     // norm; below that the consumer GEMM adds the partials itself (same order, same bits) and the launch is saved --
     // a small batch is a chain of ~1 500 dependent launches and nothing else
     const bool pre_rs = Me >= kPrecomputedRsRows;
-    const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rs, 0, d, c.eps}
-                                              : gram_norm_fusion_t{nullptr, nullptr, w.ss, d / 64, d, c.eps, quarter};
-    const gram_norm_fusion_t consume_embed{nullptr, nullptr, w.ss, d / 64, d, c.eps, 0};
-    TRY(gram_embed_ex_split(c.embed_f32, ids, 1, w.x, w.h, w.ss, d / 64, Me, d, w.pieces, st));
+    // The 16-bit copy of the residual stream carries a power-of-two factor per row (gram_norm_fusion_t.xs_in / xs_out): T5's
+    // stream leaves the IEEE-half range in trained checkpoints.  Norm point p: the producer before it scaled the copy by
+    // xs[p & 1]; the consumer divides its row scale by that and publishes the factor of the NEXT producer in xs[(p + 1) & 1].
+    int np = 0;  // norm point
+    auto produce = [&]() { return gram_norm_fusion_t{w.h, w.ss, nullptr, 0, 0, 0.f, quarter, w.xs[np & 1], nullptr}; };
+    auto consume = [&](bool from_embed) {
+      const gram_norm_fusion_t nf = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rs, 0, d, c.eps, 0, nullptr, nullptr}
+                                           : gram_norm_fusion_t{nullptr, nullptr, w.ss, d / 64, d, c.eps, from_embed ? 0 : quarter,
+                                                                w.xs[np & 1], w.xs[(np + 1) & 1]};
+      return nf;
+    };
+    auto norm_point = [&]() -> int {  // before the consumer GEMM of norm point np (big path: 1/rms / xs and the next factor)
+      return pre_rs ? gram_row_rscale_xs(w.ss, w.rs, w.xs[np & 1], w.xs[(np + 1) & 1], Me, d / 64, d, c.eps, st) : 0;
+    };
+    TRY(gram_embed_ex_xs(c.embed_f32, ids, 1, w.x, w.h, w.ss, w.xs[0], d / 64, Me, d, w.pieces, st));
     for (int i = 0; i < c.n_enc_layers; ++i) {
-      if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
+      TRY(norm_point());
       TRY(cap_inter(w, w.h, Me, d, GRAM_STAGE_ENC_ATTN, st));
-      TRY(linear(w, w.h, m->enc_wqkv[i], m->s_enc_wqkv[i], w.qkv, C_PLANAR, w.ps_qkv, Me, 3 * inner, d, GRAM_EPI_BF16, nullptr,
-                 i == 0 && !pre_rs ? &consume_embed : &consume, st));
+      {
+        const gram_norm_fusion_t nf = consume(i == 0);
+        TRY(linear(w, w.h, m->enc_wqkv[i], m->s_enc_wqkv[i], w.qkv, C_PLANAR, w.ps_qkv, Me, 3 * inner, d, GRAM_EPI_BF16, nullptr, &nf, st));
+      }
+      ++np;
       TRY(cap_planar(w, w.qkv, w.ps_qkv, GRAM_STAGE_ENC_ATTN, st));
       TRY(gram_enc_self_attn_split(w.qkv, c.enc_bias_f32, mask, w.attn, P, L, H, w.pieces, w.ps_qkv, st));
       TRY(cap_inter(w, w.attn, Me, inner, GRAM_STAGE_ENC_ATTN, st));
-      TRY(linear(w, w.attn, m->enc_wo[i], m->s_enc_wo[i], w.x, C_NONE, 0, Me, d, inner, GRAM_EPI_F32_ADD, nullptr, &produce, st));
-      if (pre_rs) TRY(gram_row_rscale(w.ss, w.rs, Me, d / 64, d, c.eps, st));
+      {
+        const gram_norm_fusion_t nf = produce();
+        TRY(linear(w, w.attn, m->enc_wo[i], m->s_enc_wo[i], w.x, C_NONE, 0, Me, d, inner, GRAM_EPI_F32_ADD, nullptr, &nf, st));
+      }
+      TRY(norm_point());
       TRY(cap_inter(w, w.h, Me, d, GRAM_STAGE_ENC_FFN, st));
-      TRY(linear(w, w.h, m->enc_wi[i], m->s_enc_wi[i], w.u, C_INTER, 0, Me, F, d, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
+      {
+        const gram_norm_fusion_t nf = consume(false);
+        TRY(linear(w, w.h, m->enc_wi[i], m->s_enc_wi[i], w.u, C_INTER, 0, Me, F, d, GRAM_EPI_BF16_RELU, nullptr, &nf, st));
+      }
+      ++np;
       TRY(cap_inter(w, w.u, Me, F, GRAM_STAGE_ENC_FFN, st));
-      TRY(linear(w, w.u, m->enc_wo2[i], m->s_enc_wo2[i], w.x, C_NONE, 0, Me, d, F, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      {
+        const gram_norm_fusion_t nf = produce();
+        TRY(linear(w, w.u, m->enc_wo2[i], m->s_enc_wo2[i], w.x, C_NONE, 0, Me, d, F, GRAM_EPI_F32_ADD, nullptr, &nf, st));
+      }
     }
   } else {  // (one piece only: gram_model_create insists on fold_norm in the two-piece mode)
     TRY(gram_embed_i64(c.embed_f32, ids, w.x, Me, d, st));
@@ -329,33 +358,60 @@ int decode_step(const gram_model* m, const Workspace& w, const int32_t* tokens, 
   if (c.fold_norm) {
     // a few rows (one user, or a handful): the streaming GEMM and its 16-column partials; the embedding writes 64-column ones
     const int quarter = R <= gram_gemm_stream_max_m() && d % 128 == 0 && inner % 128 == 0 && F % 128 == 0;
-    const gram_norm_fusion_t produce{w.hd, w.ssd, nullptr, 0, 0, 0.f, quarter};
-    const bool pre_rs = R >= kPrecomputedRsRows;  // see encoder_layers
-    const gram_norm_fusion_t consume = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rsd, 0, d, c.eps, 0}
-                                              : gram_norm_fusion_t{nullptr, nullptr, w.ssd, d / 64, d, c.eps, quarter};
-    const gram_norm_fusion_t consume_embed{nullptr, nullptr, w.ssd, d / 64, d, c.eps, 0};
-    TRY(gram_embed_ex_split(c.embed_f32, tokens, 0, w.xd, w.hd, w.ssd, d / 64, R, d, w.pieces, st));
+    const bool pre_rs = R >= kPrecomputedRsRows;  // see encoder_layers (also for the row factors xsd of the 16-bit copy)
+    int np = 0;
+    auto produce = [&]() { return gram_norm_fusion_t{w.hd, w.ssd, nullptr, 0, 0, 0.f, quarter, w.xsd[np & 1], nullptr}; };
+    auto consume = [&](bool from_embed) {
+      const gram_norm_fusion_t nf = pre_rs ? gram_norm_fusion_t{nullptr, nullptr, w.rsd, 0, d, c.eps, 0, nullptr, nullptr}
+                                           : gram_norm_fusion_t{nullptr, nullptr, w.ssd, d / 64, d, c.eps, from_embed ? 0 : quarter,
+                                                                w.xsd[np & 1], w.xsd[(np + 1) & 1]};
+      return nf;
+    };
+    auto norm_point = [&]() -> int {
+      return pre_rs ? gram_row_rscale_xs(w.ssd, w.rsd, w.xsd[np & 1], w.xsd[(np + 1) & 1], R, d / 64, d, c.eps, st) : 0;
+    };
+    TRY(gram_embed_ex_xs(c.embed_f32, tokens, 0, w.xd, w.hd, w.ssd, w.xsd[0], d / 64, R, d, w.pieces, st));
     for (int i = 0; i < c.n_dec_layers; ++i) {
-      if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      TRY(norm_point());
       TRY(cap_inter(w, w.hd, R, d, GRAM_STAGE_DEC_SELF, st));
-      TRY(linear(w, w.hd, m->dec_wqkv[i], m->s_dec_wqkv[i], w.qkvd, C_PLANAR, w.ps_qkvd, R, 3 * inner, d, GRAM_EPI_BF16, nullptr,
-                 i == 0 && !pre_rs ? &consume_embed : &consume, st));
+      {
+        const gram_norm_fusion_t nf = consume(i == 0);
+        TRY(linear(w, w.hd, m->dec_wqkv[i], m->s_dec_wqkv[i], w.qkvd, C_PLANAR, w.ps_qkvd, R, 3 * inner, d, GRAM_EPI_BF16, nullptr, &nf, st));
+      }
+      ++np;
       TRY(cap_planar(w, w.qkvd, w.ps_qkvd, GRAM_STAGE_DEC_SELF, st));
       TRY(self_attn(i, cache_layer));
       TRY(cap_inter(w, w.attnd, R, inner, GRAM_STAGE_DEC_SELF, st));
-      TRY(linear(w, w.attnd, m->dec_wo[i], m->s_dec_wo[i], w.xd, C_NONE, 0, R, d, inner, GRAM_EPI_F32_ADD, nullptr, &produce, st));
-      if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      {
+        const gram_norm_fusion_t nf = produce();
+        TRY(linear(w, w.attnd, m->dec_wo[i], m->s_dec_wo[i], w.xd, C_NONE, 0, R, d, inner, GRAM_EPI_F32_ADD, nullptr, &nf, st));
+      }
+      TRY(norm_point());
       TRY(cap_inter(w, w.hd, R, d, GRAM_STAGE_DEC_CROSS, st));
-      TRY(linear(w, w.hd, m->dec_wq_x[i], m->s_dec_wq_x[i], w.qx, C_PLANAR, w.ps_qx, R, inner, d, GRAM_EPI_BF16, nullptr, &consume, st));
+      {
+        const gram_norm_fusion_t nf = consume(false);
+        TRY(linear(w, w.hd, m->dec_wq_x[i], m->s_dec_wq_x[i], w.qx, C_PLANAR, w.ps_qx, R, inner, d, GRAM_EPI_BF16, nullptr, &nf, st));
+      }
+      ++np;
       TRY(cap_planar(w, w.qx, w.ps_qx, GRAM_STAGE_DEC_CROSS, st));
       TRY(cross_attn(i, bank_layer));
       TRY(cap_inter(w, w.attnd, R, inner, GRAM_STAGE_DEC_CROSS, st));
-      TRY(linear(w, w.attnd, m->dec_wo_x[i], m->s_dec_wo_x[i], w.xd, C_NONE, 0, R, d, inner, GRAM_EPI_F32_ADD, nullptr, &produce, st));
-      if (pre_rs) TRY(gram_row_rscale(w.ssd, w.rsd, R, d / 64, d, c.eps, st));
+      {
+        const gram_norm_fusion_t nf = produce();
+        TRY(linear(w, w.attnd, m->dec_wo_x[i], m->s_dec_wo_x[i], w.xd, C_NONE, 0, R, d, inner, GRAM_EPI_F32_ADD, nullptr, &nf, st));
+      }
+      TRY(norm_point());
       TRY(cap_inter(w, w.hd, R, d, GRAM_STAGE_DEC_FFN, st));
-      TRY(linear(w, w.hd, m->dec_wi[i], m->s_dec_wi[i], w.ud, C_INTER, 0, R, F, d, GRAM_EPI_BF16_RELU, nullptr, &consume, st));
+      {
+        const gram_norm_fusion_t nf = consume(false);
+        TRY(linear(w, w.hd, m->dec_wi[i], m->s_dec_wi[i], w.ud, C_INTER, 0, R, F, d, GRAM_EPI_BF16_RELU, nullptr, &nf, st));
+      }
+      ++np;
       TRY(cap_inter(w, w.ud, R, F, GRAM_STAGE_DEC_FFN, st));
-      TRY(linear(w, w.ud, m->dec_wo2[i], m->s_dec_wo2[i], w.xd, C_NONE, 0, R, d, F, GRAM_EPI_F32_ADD, nullptr, &produce, st));
+      {
+        const gram_norm_fusion_t nf = produce();
+        TRY(linear(w, w.ud, m->dec_wo2[i], m->s_dec_wo2[i], w.xd, C_NONE, 0, R, d, F, GRAM_EPI_F32_ADD, nullptr, &nf, st));
+      }
     }
   } else {  // (one piece only)
     TRY(gram_embed_i32(c.embed_f32, tokens, w.xd, R, d, st));

@@ -31,25 +31,62 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ ta
 }
 
 // embed_tokens for the folded-norm path: x (f32) + xb = bf16(x) + the row's sum of squares in ss[row][0]
+// embed_tokens for the folded-norm path: x (f32), its 16-bit copy xb and the row's 64-column partial sums of squares ss[row][d/64]
+// (nblk == d / 64; fewer: the row's total in ss[row][0] and zeros, the layout of round 1 -- no row factor then).
+// xs_out != NULL: the copy is x * xs, xs the power-of-two factor of the row itself (row_xscale), written to xs_out[row]
 template <typename IdT>
 __global__ __launch_bounds__(256) void embed_ex_kernel(const float* __restrict__ table, const IdT* __restrict__ ids,
                                                        float* __restrict__ x, bf16* __restrict__ xb, float* __restrict__ ss,
-                                                       int nblk, int rows, int d, int pieces) {
+                                                       float* __restrict__ xs_out, int nblk, int rows, int d, int pieces) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const f32x4* src = reinterpret_cast<const f32x4*>(table + (size_t)ids[row] * d);
   f32x4* dst = reinterpret_cast<f32x4*>(x + (size_t)row * d);
   bf16* dstb = xb + (size_t)row * d * pieces;
-  float s = 0.f;
-  for (int i = lane; i < d / 4; i += 64) {
-    const f32x4 v = src[i];
-    dst[i] = v;
-    store_pieces4(dstb, 4 * i, v, pieces);
-    s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  const bool blocks = nblk == d / 64;  // (d % 64 == 0 then: checked by the launcher)
+  f32x4 v[4];  // d <= 1024
+  float total = 0.f, minblk = INFINITY;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = lane + it * 64;  // f32x4 index: columns 4 i .. 4 i + 3, i.e. 64-column block i / 16 = 4 it + lane / 16
+    float s = 0.f;
+    if (i < d / 4) {
+      v[it] = src[i];
+      dst[i] = v[it];
+      s = (v[it][0] * v[it][0] + v[it][1] * v[it][1]) + (v[it][2] * v[it][2] + v[it][3] * v[it][3]);
+    }
+    if (blocks) {
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);  // the 16 lanes of a block all hold its sum
+      const int blk = 4 * it + (lane >> 4);
+      if (blk < nblk) {
+        if ((lane & 15) == 0) ss[(size_t)row * nblk + blk] = s;
+        minblk = fminf(minblk, s);
+      }
+      // the row total in block order, pairs first -- the order the consumers add the partials up in (row_rscale)
+      const float s1 = __shfl(s, 16, 64), s2 = __shfl(s, 32, 64), s3 = __shfl(s, 48, 64), s0 = __shfl(s, 0, 64);
+      if (4 * it < nblk) total += s0 + s1;
+      if (4 * it + 2 < nblk) total += s2 + s3;
+    } else {
+      total += s;
+    }
   }
-  s = wave_sum(s);
-  if (lane < nblk) ss[(size_t)row * nblk + lane] = lane == 0 ? s : 0.f;
+  if (blocks) {
+    minblk = wave_min(minblk);
+  } else {
+    total = wave_sum(total);
+    if (lane < nblk) ss[(size_t)row * nblk + lane] = lane == 0 ? total : 0.f;
+  }
+  const float xs = xs_out && blocks ? row_xscale(total, minblk) : 1.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = lane + it * 64;
+    if (i < d / 4) store_pieces4(dstb, 4 * i, v[it] * xs, pieces);
+  }
+  if (xs_out && lane == 0) xs_out[row] = xs;
 }
 
 // T5LayerNorm (gram_t5_modeling.py:262-276): fp32 variance, no mean subtraction, no bias.
@@ -146,17 +183,21 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(const float* __restric
 }
 
 // 1/rms per row from the residual GEMM's partial sums of squares (fixed summation order)
-__global__ __launch_bounds__(256) void row_rscale_kernel(const float* __restrict__ ss, float* __restrict__ rs, int M, int nblk,
+__global__ __launch_bounds__(256) void row_rscale_kernel(const float* __restrict__ ss, float* __restrict__ rs,
+                                                         const float* __restrict__ xs_in, float* __restrict__ xs_out, int M, int nblk,
                                                          float inv_d, float eps) {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   const float2* p = reinterpret_cast<const float2*>(ss + (size_t)m * nblk);
-  float s = 0.f;
+  float s = 0.f, mn = INFINITY;
   for (int i = 0; i < nblk / 2; ++i) {
     const float2 v = p[i];
     s += v.x + v.y;
+    mn = fminf(mn, fminf(v.x, v.y));
   }
-  rs[m] = rsqrtf(s * inv_d + eps);
+  const float r = row_rs(s, inv_d, eps);
+  rs[m] = xs_in ? r / xs_in[m] : r;  // (a power of two: exact)
+  if (xs_out) xs_out[m] = row_xscale(s, mn);
 }
 
 // Calibration probe: stream `bytes` once through every CU (16-B loads, 4 in flight per lane) and fold them
@@ -295,12 +336,17 @@ extern "C" int gram_debug_stream_read_variant(const void* src, size_t bytes, voi
   return 0;
 }
 
-extern "C" int gram_row_rscale(const float* ss, float* rs, int M, int nblk, int d, float eps, void* stream) {
-  if (M < 1 || nblk < 2 || (nblk & 1) || d < 64) return GRAM_E_ARG;
-  gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, 4.0 * M * (nblk + 1));
-  hipLaunchKernelGGL(row_rscale_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, ss, rs, M, nblk, 1.0f / (float)d, eps);
+extern "C" int gram_row_rscale_xs(const float* ss, float* rs, const float* xs_in, float* xs_out, int M, int nblk, int d, float eps,
+                                  void* stream) {
+  if (M < 1 || nblk < 2 || (nblk & 1) || d < 64 || !ss || !rs || (xs_out && xs_out == xs_in)) return GRAM_E_ARG;
+  gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, 4.0 * M * (nblk + 1 + (xs_in != nullptr) + (xs_out != nullptr)));
+  hipLaunchKernelGGL(row_rscale_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, ss, rs, xs_in, xs_out, M, nblk,
+                     1.0f / (float)d, eps);
   GRAM_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int gram_row_rscale(const float* ss, float* rs, int M, int nblk, int d, float eps, void* stream) {
+  return gram_row_rscale_xs(ss, rs, nullptr, nullptr, M, nblk, d, eps, stream);
 }
 extern "C" int gram_lse_combine(const float* lse_part, float* lse, int M, int nblk, void* stream) {
   if (M < 1 || nblk < 1) return GRAM_E_ARG;
@@ -317,15 +363,21 @@ extern "C" int gram_embed_ex(const float* table, const void* ids, int ids_are_i6
 
 extern "C" int gram_embed_ex_split(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk,
                                    int rows, int d, int pieces, void* stream) {
-  if (rows < 1 || (d & 3) || !xb || !ss || nblk < 1 || nblk > 64 || pieces < 1 || pieces > GRAM_MAX_PIECES || (pieces > 1 && (d & 31)))
+  return gram_embed_ex_xs(table, ids, ids_are_i64, x, xb, ss, nullptr, nblk, rows, d, pieces, stream);
+}
+
+extern "C" int gram_embed_ex_xs(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, float* xs_out,
+                                int nblk, int rows, int d, int pieces, void* stream) {
+  if (rows < 1 || (d & 3) || d > 1024 || !xb || !ss || nblk < 1 || nblk > 64 || pieces < 1 || pieces > GRAM_MAX_PIECES || (pieces > 1 && (d & 31)))
     return GRAM_E_ARG;
+  if (xs_out && (d % 64 != 0 || nblk != d / 64)) return GRAM_E_ARG;  // the row factor needs the true 64-column partials
   gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, (8.0 + 2.0 * pieces) * rows * d);
   if (ids_are_i64)
     hipLaunchKernelGGL(embed_ex_kernel<int64_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, (const int64_t*)ids,
-                       x, (bf16*)xb, ss, nblk, rows, d, pieces);
+                       x, (bf16*)xb, ss, xs_out, nblk, rows, d, pieces);
   else
     hipLaunchKernelGGL(embed_ex_kernel<int32_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, (const int32_t*)ids,
-                       x, (bf16*)xb, ss, nblk, rows, d, pieces);
+                       x, (bf16*)xb, ss, xs_out, nblk, rows, d, pieces);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

@@ -87,6 +87,20 @@ typedef struct {
                           sum is (q0 + q1) + (q2 + q3), which is how the 64-column epilogues add it up themselves: same bits.
                           The layout of the small-M streaming GEMM (one 16-column n-tile per workgroup); only legal for
                           M <= gram_gemm_stream_max_m() and K % 128 == 0 (GRAM_E_ARG otherwise)                  */
+  /* Range of the 16-bit copy.  T5's residual stream is unnormalised and leaves the IEEE-half range in trained checkpoints (the
+   * reference's own T5 carries the fp16 clamp for it: gram_t5_modeling.py:773-776,803-808,824-827), so xb is stored as the pieces
+   * of x[m] * xs[m], xs[m] a POWER OF TWO per row (exact), and the consumer's row scale is divided by it (exact):
+   *   producer: xs_in f32 [M] -- xb_out[m] = pieces(x[m] * xs_in[m]); NULL = 1
+   *   consumer: xs_in f32 [M] -- the factor the producer of A applied: every output row is scaled by rsqrt(..) / xs_in[m].  Ignored
+   *             when nblk_in == 0 (ss_in then already holds rsqrt(..) / xs: gram_row_rscale_xs).
+   *             xs_out f32 [M] or NULL -- the workgroups of the first n-tile also write the factor for the NEXT producer from the
+   *             partials they have just added up: with typ^2 = (smallest 64-column partial of row m) / 64 -- the ordinary magnitude
+   *             of the row; the few outlier features of a T5 row dominate its rms but not its quietest block -- the power of two
+   *             that puts typ * xs into [2^-2, 2^-1), capped so that sqrt(sum of squares) * xs <= 2^10, clamped to [2^-40, 2^20].
+   *             Two IEEE-half pieces then hold 22 bits of every element down to half the ordinary magnitude (error floor 2^-23 of
+   *             it below) and up to 1.3e5 times it.  xs_out must not alias xs_in. */
+  const float* xs_in;
+  float* xs_out;
 } gram_norm_fusion_t;
 /* Largest M the streaming small-M GEMM takes (0: switched off, GRAM_GEMM_STREAM=0 or a forced variant). */
 int gram_gemm_stream_max_m(void);
@@ -94,7 +108,11 @@ int gram_gemm_bf16_ex(const void* A, const void* W, void* C, int M, int N, int K
                       const gram_kv_bank_t* bank_host, const gram_norm_fusion_t* nf_host, void* stream);
 /* rs[m] = rsqrt(sum_b ss[m][b] / d + eps); a consumer may take it directly with nblk_in = 0 (ss_in = rs). */
 int gram_row_rscale(const float* ss, float* rs, int M, int nblk, int d, float eps, void* stream);
-/* embed_tokens for the folded path: x (f32), xb = bf16(x), ss[m][0] = sum x^2 (other blocks 0). */
+/* The same with the row factors of the 16-bit copy (gram_norm_fusion_t): rs[m] = rsqrt(..) / xs_in[m] (xs_in NULL = 1) and, when
+ * xs_out is given, xs_out[m] = the factor for the next producer (see xs_out above).  xs_out may not alias xs_in. */
+int gram_row_rscale_xs(const float* ss, float* rs, const float* xs_in, float* xs_out, int M, int nblk, int d, float eps, void* stream);
+/* embed_tokens for the folded path: x (f32), xb = bf16(x), ss[m][b] = the sum of squares of 64-column block b when nblk == d / 64
+ * (any other nblk: the row's total in ss[m][0], zeros behind it). */
 int gram_embed_ex(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk, int rows,
                   int d, void* stream);
 
@@ -135,6 +153,10 @@ int gram_gemm_bf16_lse_split(const void* A, const void* W, float* logits, float*
  * inputs, the bank and the cache are planar, *_pstride elements apart. */
 int gram_embed_ex_split(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, int nblk, int rows,
                         int d, int pieces, void* stream);
+/* ... with the row factor of the 16-bit copy (gram_norm_fusion_t.xs_in of the consumer that follows): xs_out[m] = the factor of the
+ * row's OWN rms, xb = pieces(x * xs_out[m]).  xs_out NULL = gram_embed_ex_split. */
+int gram_embed_ex_xs(const float* table, const void* ids, int ids_are_i64, float* x, void* xb, float* ss, float* xs_out, int nblk,
+                     int rows, int d, int pieces, void* stream);
 int gram_rmsnorm_bf16_split(const float* x, const float* w, void* out_bf16, int rows, int d, float eps, float scale,
                             const float* pos, int N, int L, const int32_t* passage_map, int pieces, void* stream);
 int gram_enc_self_attn_split(const void* qkv, const float* bias, const uint8_t* mask, void* out, int P, int L, int H,

@@ -700,4 +700,4 @@ def test_folded_layernorm_gemms(G, M):
     sse = torch.empty(77, d // 64, device=G.DEV)
     _lib.check(L_.gram_embed_ex(G.p(table), G.p(ids), 1, G.p(xe), G.p(xbe), G.p(sse), d // 64, 77, d, G.stream()), "embed_ex")
     assert torch.equal(xe, table[ids]) and torch.equal(xbe, table[ids].to(G.DT))
-    assert torch.allclose(sse.sum(-1), (xe * xe).sum(-1), rtol=1e-5) and bool((sse[:, 1:] == 0).all())
+    assert torch.allclose(sse, (xe * xe).view(77, d // 64, 64).sum(-1), rtol=1e-5)  # true 64-column partials

@@ -236,16 +236,58 @@ def test_generate_vs_oracle(gpu, name, B, N, L, K, n_items, depth):
     _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=SCORE_TOL)
 
 
+@pytest.mark.parametrize("kind", ["whole_table_3e5", "outlier_features"])
+def test_large_residual_stream_matches_the_oracle(gpu, kind):
+    """T5's residual stream leaves the IEEE-half range in trained checkpoints (the reference's own T5 carries the fp16 clamp for it:
+    gram_t5_modeling.py:773-776,803-808,824-827).  The 16-bit copy of the stream carries a power-of-two factor per row
+    (gram_norm_fusion_t.xs_in / xs_out), so a model whose embedding table puts the stream at ~3e5 -- or whose rows carry outlier features
+    1e4 times the ordinary ones -- is scored like any other: same top-K as the fp32 oracle at the ordinary score tolerance."""
+    from gram_amd import T5Config
+    from gram_amd.utils import generation_trie as gt
+    oc = O.OracleConfig(vocab_size=256, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2, max_item_num=5,
+                        tie_word_embeddings=False)  # (an untied lm_head: the logits keep their ordinary scale)
+    gc = T5Config(vocab_size=256, d_model=128, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=2, max_item_num=5,
+                  tie_word_embeddings=False)
+    sd = O.init_state_dict(oc, 3)
+    emb = sd["shared.weight"].clone()
+    if kind == "whole_table_3e5":
+        emb *= 3.0e5
+    else:
+        emb[:, [7, 70, 101]] *= 1.0e4
+    for k in ("shared.weight", "encoder.encoder.embed_tokens.weight", "decoder.embed_tokens.weight"):
+        sd[k] = emb
+    m = gpu.create_model("gram", gc)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    g = torch.Generator().manual_seed(5)
+    B, N, L, K = 4, 3, 32, 6
+    ids, mask = _inputs(g, B, N, L, min(oc.vocab_size, 32100))
+    cands = _random_items(g, 40, 3, 4, 60)
+    max_length = max(len(c) for c in cands)
+    ref = O.generate(sd, oc, ids, mask, max_length, O.prefix_allowed_tokens_fn(O.Trie(cands)), K, K, 1.0)
+    out = m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max_length,
+                     prefix_allowed_tokens_fn=gt.prefix_allowed_tokens_fn(gt.Trie(cands)), num_beams=K, num_return_sequences=K,
+                     length_penalty=1.0)
+    _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=SCORE_TOL)
+    # one user at a time: the row factors are a function of the row alone (batch invariance, bit for bit)
+    one = m.generate(input_ids=ids[1:2].to(DEV), attention_mask=mask[1:2].to(DEV), max_length=max_length,
+                     prefix_allowed_tokens_fn=gt.prefix_allowed_tokens_fn(gt.Trie(cands)), num_beams=K, num_return_sequences=K,
+                     length_penalty=1.0)
+    w = min(one["sequences"].shape[1], out["sequences"].shape[1])
+    assert torch.equal(one["sequences"][:, :w], out["sequences"][K:2 * K, :w])
+    assert torch.equal(one["sequences_scores"], out["sequences_scores"][K:2 * K])
+
+
 def test_activation_overflow_of_the_half_pieces_is_an_error(gpu):
-    """IEEE-half pieces hold |x| <= 65 504.  A model whose residual stream leaves that range must not return
-    garbage rankings: generate() raises (GRAM_E_NONFINITE) and names the bfloat16 build as the way out."""
+    """Non-finite arithmetic must not return a garbage ranking: generate() raises GRAM_E_NONFINITE.  (The half range of the pieces
+    alone no longer gets there -- test_large_residual_stream_matches_the_oracle -- so the stream here leaves fp32 itself.)"""
     from gram_amd import _lib
     from gram_amd.utils import generation_trie as gt
     if _lib.piece_dtype() != torch.float16:
         pytest.skip("bfloat16 build: the pieces have fp32's exponent range")
     oc, gc = _cfgs("tiny")
     sd = O.init_state_dict(oc, 3)
-    big = sd["shared.weight"] * 1.0e7  # embeddings (the residual stream's first value) far outside the half range
+    big = sd["shared.weight"] * 1.0e30  # embeddings whose squares leave fp32 itself: no row factor can help (the sums of squares are inf)
     for k in ("shared.weight", "encoder.encoder.embed_tokens.weight", "decoder.embed_tokens.weight", "lm_head.weight"):  # (one tied table)
         sd[k] = big
     m = gpu.create_model("gram", gc)

@@ -84,6 +84,79 @@ def test_split_gemm_epilogues(G, M, N, K):
     assert split_gemm(G, A, W, f, M, N, K, _lib.EPI_F32, out_scale=0.3) == _lib.E_ARG
 
 
+def _host_row_xscale(ss):
+    """gram_norm_fusion_t.xs_out restated on the host from the 64-column partials [M][nblk] (fp32, the device's own floats)."""
+    s = torch.zeros(ss.shape[0], dtype=torch.float32, device=ss.device)
+    for i in range(ss.shape[1] // 2):
+        s = s + (ss[:, 2 * i] + ss[:, 2 * i + 1])
+    want = 0.25 * torch.rsqrt(ss.min(dim=1).values / 64.0)
+    cap = 1024.0 * torch.rsqrt(s)
+    e = torch.floor(torch.log2(torch.minimum(want, cap).double())).clamp(-40, 20)
+    return torch.pow(2.0, e).float()
+
+
+@pytest.mark.parametrize("pieces", [2, 1])
+@pytest.mark.parametrize("M", [20, 300, 1500, 33000])  # skinny / streaming, 64- and 128-row tiles, the ping-pong kernel
+def test_row_factors_of_the_16_bit_residual_copy(G, M, pieces):
+    """gram_norm_fusion_t.xs_in / xs_out: residual rows of magnitude 1e-2 .. 3e5 with outlier features (what a trained T5 stream looks
+    like; IEEE half ends at 65 504) go producer -> consumer with a power-of-two factor per row on the 16-bit copy.  The consumer's
+    output matches the fp64 norm + Linear at the two-piece precision for EVERY row, the published factors are the documented function
+    of the partials, and without the factors the large rows are lost (f16 build)."""
+    from gram_amd import _lib
+    d, Kp, F = 768, 128, 256
+    g = torch.Generator().manual_seed(M + pieces)
+    mag = torch.pow(10.0, torch.rand(M, 1, generator=g) * 7.5 - 2.0)          # 1e-2 .. 3e5 per row
+    base = torch.randn(M, d, generator=g) * mag
+    base[:, [5, 300, 701]] *= 300.0                                          # outlier features (dominate the rms)
+    base = base.clamp(-3.0e8, 3.0e8).to(G.DEV)
+    a32 = (torch.randn(M, Kp, generator=g) * mag.clamp(max=1.0e3)).to(G.DEV)   # the sublayer's output (itself a 16-bit operand)
+    wo32, w232 = _r(d, Kp, seed=3, scale=Kp ** -0.5).to(G.DEV), _r(F, d, seed=4, scale=d ** -0.5).to(G.DEV)
+    enc = G.inter if pieces == 2 else G.bf
+    A, Wo, W2 = enc(a32), enc(wo32), enc(w232)
+    sp = _lib.Split(pieces, int(pieces == 2), 0, 0, 1.0)
+    lda = pieces * Kp
+    # xs0: the factor the PREVIOUS norm point would have published -- from the rows as they stand before the add
+    xs0 = _host_row_xscale((base * base).view(M, d // 64, 64).sum(-1))
+    outs = {}
+    for use_xs in (True, False):
+        x = base.clone()
+        xb = torch.zeros(M, pieces * d, dtype=G.DT, device=G.DEV)
+        ss = torch.full((M, d // 64), float("nan"), dtype=torch.float32, device=G.DEV)
+        xs1 = torch.zeros(M, device=G.DEV)
+        prod = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0, 0, xs0.data_ptr() if use_xs else None, None)
+        _lib.check(G.lib().gram_gemm_bf16_split(G.p(A), G.p(Wo), G.p(x), M, d, Kp, lda, d, _lib.EPI_F32_ADD, None, C.byref(prod), C.byref(sp),
+                                                G.stream()), "producer")
+        y = torch.zeros(M, pieces * F, dtype=G.DT, device=G.DEV)
+        if M >= 32768:  # the ping-pong kernels take 1/rms (already divided by the factor) per row
+            rs = torch.zeros(M, device=G.DEV)
+            _lib.check(G.lib().gram_row_rscale_xs(G.p(ss), G.p(rs), G.p(xs0) if use_xs else None, G.p(xs1), M, d // 64, d, 1e-6, G.stream()),
+                       "row_rscale_xs")
+            cons = _lib.NormFusion(None, None, rs.data_ptr(), 0, d, 1e-6)
+        else:
+            cons = _lib.NormFusion(None, None, ss.data_ptr(), d // 64, d, 1e-6, 0, xs0.data_ptr() if use_xs else None, xs1.data_ptr())
+        _lib.check(G.lib().gram_gemm_bf16_split(G.p(xb), G.p(W2), G.p(y), M, F, d, pieces * d, pieces * F, _lib.EPI_BF16, None, C.byref(cons),
+                                                C.byref(sp), G.stream()), "consumer")
+        torch.cuda.synchronize()
+        outs[use_xs] = (x, ss, xs1, G.join_inter(y) if pieces == 2 else y.double())
+    x, ss, xs1, y = outs[True]
+    xr = base.double() + a32.double() @ wo32.double().T
+    ref = (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6)) @ w232.double().T
+    row_err = (y - ref).norm(dim=1) / ref.norm(dim=1)
+    bound = (tol(G) if pieces == 2 else 2e-3 if G.F16 else 1.5e-2)
+    print(f"\n[row factors] M={M} pieces={pieces}: worst row error {float(row_err.max()):.2e} (bound {bound:.1e})")
+    assert bool(torch.isfinite(y).all()) and float(row_err.max()) < bound
+    # the published factors: the documented function of the partials (v_rsq_f32 vs torch.rsqrt may differ in the last bit: at most a
+    # handful of rows sit on a power-of-two boundary)
+    host = _host_row_xscale(ss)
+    ratio = (xs1 / host).cpu()
+    assert bool(((ratio == 1) | (ratio == 2) | (ratio == 0.5)).all()) and float((ratio == 1).float().mean()) > 0.99
+    assert bool((torch.log2(xs1) == torch.log2(xs1).round()).all())
+    if G.F16:  # without the factors the rows beyond the half range are lost; the ones inside it are the same values
+        y0 = outs[False][3]
+        big = (xr.abs().max(dim=1).values > 7.0e4)
+        assert big.any() and not bool(torch.isfinite(y0[big]).all())
+
+
 def test_split_gemm_kv_bank(G):
     from gram_amd import _lib
     B, S, H, layers, d = 3, 96, 2, 2, 256
