@@ -302,6 +302,11 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # (outside the timed region) which device each rank ran on: one GPU per rank unless --share-device
+        devs = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=tmax.device)
+        dev_list = [torch.zeros_like(devs) for _ in range(world)]
+        dist.all_gather(dev_list, devs)
+        exchange["devices"] = [int(t.item()) for t in dev_list]
 
     pp_ghz = C.c_double(0.0)  # time-weighted in-kernel clock of the ping-pong GEMM launches of the timed region (gram_hip.h)
     _lib.check(lib.gram_prof_pp_clock(C.byref(pp_ghz), 1), "pp_clock")
