@@ -270,6 +270,7 @@ def main():
     if prof:
         launches_per_step = 40 * (cfg.num_layers + cfg.num_decoder_layers * max_length) + 64
         _lib.check(lib.gram_prof_enable(sum(1 << k for k in kinds.values()), launches_per_step * args.steps), "prof_enable")
+    lib.gram_prof_pp_clock_enable(1)  # the ping-pong GEMM's clock stamps: a diagnostic, off in the product path (gram_hip.h)
     _lib.check(lib.gram_prof_pp_clock(None, 1), "pp_clock reset")  # (synchronises; outside the timed region)
     barrier()
     t0 = time.perf_counter()
@@ -310,6 +311,7 @@ def main():
 
     pp_ghz = C.c_double(0.0)  # time-weighted in-kernel clock of the ping-pong GEMM launches of the timed region (gram_hip.h)
     _lib.check(lib.gram_prof_pp_clock(C.byref(pp_ghz), 1), "pp_clock")
+    lib.gram_prof_pp_clock_enable(0)
     kernel = {}
     if prof:
         for name, kind in kinds.items():
@@ -454,11 +456,6 @@ def main():
                                      num_beams=K, num_return_sequences=K, length_penalty=1.0)
         one()
         extras["batch1_ms_per_generate"] = 1e3 * timed(one, 10)
-        lib.gram_debug_set_graph(1)
-        for _ in range(3):  # (the second call of a small shape captures its HIP graph, later ones replay it)
-            one()
-        extras["batch1_ms_per_generate_hip_graph_replay"] = 1e3 * timed(one, 10)
-        lib.gram_debug_set_graph(-1)
         # (3) the other precision modes on the same batch (weights re-packed; not the headline arithmetic)
         extras["users_per_s_other_modes"] = {}
         for mode in sorted(m_ for m_ in PIECES if m_.startswith("f16") == args.precision.startswith("f16")):

@@ -131,10 +131,10 @@ SIGNATURES = {
     "gram_encode_fused": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, C.c_int, vp, vp]),
     "gram_decode_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, vp, vp]),
     "gram_prof_pp_clock": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
+    "gram_prof_pp_clock_enable": (C.c_int, [C.c_int]),
     "gram_debug_set_gemm_variant": (C.c_int, [C.c_int]),
     "gram_gemm_stream_max_m": (C.c_int, []),
     "gram_debug_set_live_rows": (C.c_int, [C.c_int]),
-    "gram_debug_set_graph": (C.c_int, [C.c_int]),
     "gram_debug_set_stage_pieces": (C.c_int, [C.POINTER(i32), C.c_int]),
     "gram_debug_stream_read": (C.c_int, [vp, C.c_size_t, vp, vp]),
     "gram_debug_stream_read_variant": (C.c_int, [vp, C.c_size_t, vp, C.c_int, C.c_int, vp]),
@@ -164,6 +164,13 @@ SIGNATURES = {
     "gram_generate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32, C.POINTER(Trie),
                                 vp, i64, vp, vp, C.POINTER(i32), vp]),
 }
+
+# the `_f16` aliases (gram_hip.h): same signatures as the `_bf16` names
+for _old, _new in (("gram_gemm_bf16", "gram_gemm_f16"), ("gram_gemm_bf16_ex", "gram_gemm_f16_ex"), ("gram_gemm_bf16_split", "gram_gemm_f16_split"),
+                   ("gram_gemm_bf16_lse", "gram_gemm_f16_lse"), ("gram_gemm_bf16_lse_split", "gram_gemm_f16_lse_split"),
+                   ("gram_rmsnorm_bf16", "gram_rmsnorm_f16"), ("gram_rmsnorm_bf16_map", "gram_rmsnorm_f16_map"),
+                   ("gram_rmsnorm_bf16_split", "gram_rmsnorm_f16_split")):
+    SIGNATURES[_new] = SIGNATURES[_old]
 
 _lib = None
 

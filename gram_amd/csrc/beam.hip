@@ -115,7 +115,7 @@ __global__ void beam_init_kernel(gram_beam_state_t st, gram_trie_t tr, int start
 template <int NTHR>
 __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, gram_trie_t tr, const float* __restrict__ logits,
                                                         const float* __restrict__ lse, int V, int cur_len, int nc_max, int rows_per_user,
-                                                        const bf16* __restrict__ hd, const bf16* __restrict__ emb, int d,
+                                                        const p16* __restrict__ hd, const p16* __restrict__ emb, int d,
                                                         const int32_t* __restrict__ rowpos, int pieces,
                                                         const float* __restrict__ emb32) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
       float acc = 0.f;
       if (act && emb32) {
         // two-piece mode (gram_split_t): h = fp32 sum of its pieces (smallest first; the row is interleaved, [2 d]), E = the fp32 lm_head row
-        const bf16* hrow = hd + (size_t)lr * d * pieces;
+        const p16* hrow = hd + (size_t)lr * d * pieces;
         const int c0 = sub * per;
         auto hoff = [&](int n, int pc) { return pieces == 2 ? inter_off(n, pc) : n; };
         const f32x4* ep = reinterpret_cast<const f32x4*>(emb32 + (size_t)tok * d + sub * per);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
           // 32 elements per lane and trip, every load of the trip in flight together (one 8-element step per trip is a dependent
           // round trip each: 12 of them per candidate at d = 768); same sums in the same order as the loop below
           for (; i + 32 <= per; i += 32) {
-            bf16x8 hb0[4], hb1[4];
+            p16x8 hb0[4], hb1[4];
             f32x4 ev[8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
         for (; i < per; i += 8) {
           float hv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           for (int pc = pieces - 1; pc >= 0; --pc) {
-            const bf16x8 hb = ld_global_b128(hrow + hoff(c0 + i, pc));
+            const p16x8 hb = ld_global_b128(hrow + hoff(c0 + i, pc));
 #pragma unroll
             for (int e = 0; e < 8; ++e) hv[e] += (float)hb[e];
           }
@@ -236,11 +236,11 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
           for (int e = 0; e < 4; ++e) acc += hv[4 + e] * e1[e];
         }
       } else if (act) {
-        const bf16* hp = hd + (size_t)lr * d + sub * per;
-        const bf16* ep = emb + (size_t)tok * d + sub * per;
+        const p16* hp = hd + (size_t)lr * d + sub * per;
+        const p16* ep = emb + (size_t)tok * d + sub * per;
         int i = 0;
         for (; i + 32 <= per; i += 32) {  // 8 loads in flight per lane (one load pair per iteration is a dependent round trip each)
-          bf16x8 hv[4], ev[4];
+          p16x8 hv[4], ev[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             hv[u] = ld_global_b128(hp + i + 8 * u);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
             for (int e = 0; e < 8; ++e) acc += (float)hv[u][e] * (float)ev[u][e];  // same order as the scalar loop
         }
         for (; i < per; i += 8) {
-          const bf16x8 hv = ld_global_b128(hp + i), ev = ld_global_b128(ep + i);
+          const p16x8 hv = ld_global_b128(hp + i), ev = ld_global_b128(ep + i);
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc += (float)hv[e] * (float)ev[e];
         }
@@ -709,10 +709,10 @@ static int launch_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, 
   static const int wide_max_b = getenv("GRAM_BEAM_WIDE_MAXB") ? atoi(getenv("GRAM_BEAM_WIDE_MAXB")) : 128;
   if (st->B <= wide_max_b)
     hipLaunchKernelGGL(beam_step_kernel<1024>, dim3(st->B), dim3(1024), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc,
-                       rows_per_user, (const bf16*)hd, (const bf16*)emb, d, rowpos, pieces, emb32);
+                       rows_per_user, (const p16*)hd, (const p16*)emb, d, rowpos, pieces, emb32);
   else
     hipLaunchKernelGGL(beam_step_kernel<256>, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc,
-                       rows_per_user, (const bf16*)hd, (const bf16*)emb, d, rowpos, pieces, emb32);
+                       rows_per_user, (const p16*)hd, (const p16*)emb, d, rowpos, pieces, emb32);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

@@ -9,17 +9,18 @@
 // f16 subnormal inputs: profiles/r03_mfma_f16_denorm_probe.json) -- measured: no rank flip against the fp32 reference on either
 // test population, where two bf16 pieces flip (profiles/r03a_precision_*).  The narrower exponent range is handled by power-of-two
 // weight scales (gram_split_t.out_scale).  `make PIECE=bf16` (GRAM_PIECE_BF16) builds the same sources on bfloat16 for A/B runs.
-// The identifier of the type is `bf16` in both builds (as in the C ABI's entry-point names, which predate the switch).
+// The type is spelled `p16` ("piece, 16 bits") in the sources; the C ABI's entry points carry `_bf16` in their names (they predate the
+// switch) AND `_f16` aliases (gram_hip.h) that refuse to run in a library built on the other type.
 #ifdef GRAM_PIECE_BF16
-typedef __bf16 bf16;
+typedef __bf16 p16;
 #define GRAM_PIECE_FORMAT 0
 #else
-typedef _Float16 bf16;
+typedef _Float16 p16;
 #define GRAM_PIECE_FORMAT 1
 #define GRAM_F16 1
 #endif
-typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef p16 p16x8 __attribute__((ext_vector_type(8)));
+typedef p16 p16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // largest M the streaming small-M GEMM ever takes (gemm.hip clamps GRAM_GEMM_STREAM_MAXM to it; generate.hip sizes the 16-column
@@ -37,7 +38,7 @@ constexpr int GRAM_STREAM_MAX_M_LIMIT = 4096;
 
 // D[16x16] += A[16x32] * B[32x16]; lane l supplies A[row l&15][k 8(l>>4)..+7], B[k 8(l>>4)..+7][col l&15];
 // lane l receives D[row 4(l>>4)+j][col l&15] in element j.
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+__device__ __forceinline__ f32x4 mfma16(p16x8 a, p16x8 b, f32x4 c) {
 #ifdef GRAM_F16
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 #else
@@ -45,27 +46,27 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 #endif
 }
 
-__device__ __forceinline__ bf16x8 ld_global_b128(const bf16* p) {
-  return *reinterpret_cast<const bf16x8*>(p);
+__device__ __forceinline__ p16x8 ld_global_b128(const p16* p) {
+  return *reinterpret_cast<const p16x8*>(p);
 }
 
 // streaming (nontemporal) loads for data that is read once per sweep (nothing to keep in the L2 / MALL for)
 #ifndef GRAM_ATTN_NT
 #define GRAM_ATTN_NT 0  // A/B build hook: 1 = the self-attention kernels read q/k/v and the cache with the nt hint (measured slower: encoder 56.2 -> 58.0 ms, decoder 42.4 -> 47.4 ms per step -- the K beams of a user share cache rows through the L2)
 #endif
-__device__ __forceinline__ bf16x8 ld_stream_b128(const bf16* p) {
-  if constexpr (GRAM_ATTN_NT != 0) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
-  else return *reinterpret_cast<const bf16x8*>(p);
+__device__ __forceinline__ p16x8 ld_stream_b128(const p16* p) {
+  if constexpr (GRAM_ATTN_NT != 0) return __builtin_nontemporal_load(reinterpret_cast<const p16x8*>(p));
+  else return *reinterpret_cast<const p16x8*>(p);
 }
-__device__ __forceinline__ bf16x4 ld_stream_b64(const bf16* p) {
-  if constexpr (GRAM_ATTN_NT != 0) return __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p));
-  else return *reinterpret_cast<const bf16x4*>(p);
+__device__ __forceinline__ p16x4 ld_stream_b64(const p16* p) {
+  if constexpr (GRAM_ATTN_NT != 0) return __builtin_nontemporal_load(reinterpret_cast<const p16x4*>(p));
+  else return *reinterpret_cast<const p16x4*>(p);
 }
 
-__device__ __forceinline__ bf16x8 zero_bf16x8() {
-  bf16x8 z;
+__device__ __forceinline__ p16x8 zero_bf16x8() {
+  p16x8 z;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) z[i] = (bf16)0.0f;
+  for (int i = 0; i < 8; ++i) z[i] = (p16)0.0f;
   return z;
 }
 
@@ -86,9 +87,9 @@ __device__ __forceinline__ void split2_pair(float a, float b, uint32_t& hi, uint
   const f32x2_ r = {ra, rb};
   lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, h16x2_));
 #else
-  typedef bf16 b16x2_ __attribute__((ext_vector_type(2)));
-  b16x2_ h = {(bf16)a, (bf16)b};
-  b16x2_ l = {(bf16)(a - (float)h[0]), (bf16)(b - (float)h[1])};
+  typedef p16 b16x2_ __attribute__((ext_vector_type(2)));
+  b16x2_ h = {(p16)a, (p16)b};
+  b16x2_ l = {(p16)(a - (float)h[0]), (p16)(b - (float)h[1])};
   hi = __builtin_bit_cast(uint32_t, h);
   lo = __builtin_bit_cast(uint32_t, l);
 #endif

@@ -58,8 +58,8 @@ constexpr int XA_TILE = 4096;  // one K tile or one V^T tile of a 32-key step, p
 // (user, head) and nothing is merged); R = ring stages per wave
 template <int NT, bool LIVE, int S, int NW, int R>
 __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
-    const bf16* __restrict__ q, const bf16* __restrict__ kbank, const bf16* __restrict__ vtbank,
-    const uint8_t* __restrict__ mask, bf16* __restrict__ out, int K, int H, int Sk, const int32_t* __restrict__ users,
+    const p16* __restrict__ q, const p16* __restrict__ kbank, const p16* __restrict__ vtbank,
+    const uint8_t* __restrict__ mask, p16* __restrict__ out, int K, int H, int Sk, const int32_t* __restrict__ users,
     const int32_t* __restrict__ rowpos, long q_pstride, long bank_pstride, const uint32_t* __restrict__ key_bits) {
   using T = SplitTab<S>;
   constexpr int NB = NT * 16;                     // padded beams
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
   const char* vt = reinterpret_cast<const char*>(vtbank + ((size_t)b * H + h) * 64 * Sk);
   const uint8_t* mk = mask + (size_t)b * Sk;
 
-  bf16x8 qf[S][NT][2];  // query fragments: loaded once the ring is primed (below)
+  p16x8 qf[S][NT][2];  // query fragments: loaded once the ring is primed (below)
   f32x4 o[4][NT];
   float m[NT], l[NT];
 #pragma unroll
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
   // A stage is consumed in two phases: read_frags pulls every K and V^T fragment of the step out of the ring slot into registers, and
   // once those reads have returned the slot is re-filled (the next step's DMAs are in flight during the whole of `math`, which
   // works on registers only) -- with one stage per wave and the issue after the math, a wave had nothing in flight while it computed.
-  bf16x8 kf[S][2][2], vf[S][4];
+  p16x8 kf[S][2][2], vf[S][4];
   auto read_k = [&](int slot) {
     const char* stg = smem + wave * RING + slot * STAGE;
 #pragma unroll
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
 #pragma unroll
         for (int kd = 0; kd < 2; ++kd) {
           const int r = krow + 4 * t;
-          kf[pc][t][kd] = *reinterpret_cast<const bf16x8*>(stg + pc * PSTR + r * 128 + (((g + 4 * kd) ^ ksw(r)) << 4));
+          kf[pc][t][kd] = *reinterpret_cast<const p16x8*>(stg + pc * PSTR + r * 128 + (((g + 4 * kd) ^ ksw(r)) << 4));
         }
   };
   auto read_v = [&](int slot) {
@@ -225,14 +225,14 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int d = 16 * mt + c;
-        vf[pc][mt] = *reinterpret_cast<const bf16x8*>(stg + pc * PSTR + VOFF + d * 64 + ((g ^ vsw(d)) << 4));
+        vf[pc][mt] = *reinterpret_cast<const p16x8*>(stg + pc * PSTR + VOFF + d * 64 + ((g ^ vsw(d)) << 4));
       }
   };
   auto read_frags = [&](int slot) {
     read_k(slot);
     read_v(slot);
   };
-  bf16x8 pf[S][NT];  // exp(S^T - max) of the step, as pieces: the B operand of O^T += V^T P^T
+  p16x8 pf[S][NT];  // exp(S^T - max) of the step, as pieces: the B operand of O^T += V^T P^T
   auto math_qk = [&](int step) {
     const uint32_t kword = step < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)kb0, step) : (uint32_t)__builtin_amdgcn_readlane((int)kb1, step - 64);
     const uint32_t kbits = kword >> (8 * g);  // this lane's keys 8g + 4t + j
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
           ps += e;
 #pragma unroll
           for (int pc = 0; pc < S; ++pc) {
-            const bf16 eb = (bf16)e;
+            const p16 eb = (p16)e;
             pf[pc][nt][4 * t + j] = eb;
             e -= (float)eb;
           }
@@ -441,14 +441,14 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
           f32x4 v = o[mt][nt] * inv;
 #pragma unroll
           for (int pc = 0; pc < S; ++pc) {
-            bf16x4 r;
+            p16x4 r;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              r[e] = (bf16)v[e];
+              r[e] = (p16)v[e];
               v[e] -= (float)r[e];
             }
             const int n = h * 64 + 16 * mt + 4 * g;  // (S == 2: interleaved rows [2 * inner], the O GEMM's A operand)
-            *reinterpret_cast<bf16x4*>(out + (size_t)orow * inner * S + (S == 2 ? inter_off(n, pc) : n)) = r;
+            *reinterpret_cast<p16x4*>(out + (size_t)orow * inner * S + (S == 2 ? inter_off(n, pc) : n)) = r;
           }
         }
       }
@@ -492,14 +492,14 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     if (orow >= 0) {
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) {
-        bf16x4 r;
+        p16x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          r[e] = (bf16)v[e];
+          r[e] = (p16)v[e];
           v[e] -= (float)r[e];
         }
         const int n = h * 64 + d4;
-        *reinterpret_cast<bf16x4*>(out + (size_t)orow * inner * S + (S == 2 ? inter_off(n, pc) : n)) = r;
+        *reinterpret_cast<p16x4*>(out + (size_t)orow * inner * S + (S == 2 ? inter_off(n, pc) : n)) = r;
       }
     }
   }
@@ -523,11 +523,11 @@ int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* ma
     attr_set = true;
   }
   if (users)
-    hipLaunchKernelGGL((cross_attn_kernel<NT, true, S, NW, R>), dim3(H, B), dim3(NW * 64), smem, st, (const bf16*)q, (const bf16*)k,
-                       (const bf16*)vt, mask, (bf16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits);
+    hipLaunchKernelGGL((cross_attn_kernel<NT, true, S, NW, R>), dim3(H, B), dim3(NW * 64), smem, st, (const p16*)q, (const p16*)k,
+                       (const p16*)vt, mask, (p16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits);
   else
-    hipLaunchKernelGGL((cross_attn_kernel<NT, false, S, NW, R>), dim3(H, B), dim3(NW * 64), smem, st, (const bf16*)q, (const bf16*)k,
-                       (const bf16*)vt, mask, (bf16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits);
+    hipLaunchKernelGGL((cross_attn_kernel<NT, false, S, NW, R>), dim3(H, B), dim3(NW * 64), smem, st, (const p16*)q, (const p16*)k,
+                       (const p16*)vt, mask, (p16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -629,9 +629,9 @@ __global__ __launch_bounds__(128) void mask_key_bits_kernel(const uint8_t* __res
 
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ kcache,
-                                                            bf16* __restrict__ vcache, const int32_t* __restrict__ anc,
-                                                            const float* __restrict__ bias, bf16* __restrict__ out, int R,
+__global__ __launch_bounds__(256) void dec_self_attn_kernel(const p16* __restrict__ qkv, p16* __restrict__ kcache,
+                                                            p16* __restrict__ vcache, const int32_t* __restrict__ anc,
+                                                            const float* __restrict__ bias, p16* __restrict__ out, int R,
                                                             int H, int t, const int32_t* __restrict__ rows, long qkv_ps,
                                                             long cache_ps) {
   // live-row step (rows != NULL): qkv/out are indexed by the compact row, the cache and the ancestor table by the
@@ -641,16 +641,16 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restri
   const int rc = blockIdx.x, i = threadIdx.x;  // i: 16 threads per head, 4 dims each
   const int r = rows ? rows[rc] : rc;
   const int inner = H * 64, h = i >> 4;
-  const bf16* row = qkv + (size_t)rc * 3 * inner + 4 * i;
+  const p16* row = qkv + (size_t)rc * 3 * inner + 4 * i;
   // values as the fp32 sum of their pieces (exact for two pieces, one rounding for three); the pieces themselves go to the cache
   float qf[4] = {0.f, 0.f, 0.f, 0.f}, kn[4] = {0.f, 0.f, 0.f, 0.f}, vn[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int pc = S - 1; pc >= 0; --pc) {  // smallest piece first
-    const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(row + pc * qkv_ps);
-    const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(row + pc * qkv_ps + inner);
-    const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(row + pc * qkv_ps + 2 * inner);
-    *reinterpret_cast<bf16x4*>(kcache + pc * cache_ps + ((size_t)t * R + r) * inner + 4 * i) = k4;
-    *reinterpret_cast<bf16x4*>(vcache + pc * cache_ps + ((size_t)t * R + r) * inner + 4 * i) = v4;
+    const p16x4 q4 = *reinterpret_cast<const p16x4*>(row + pc * qkv_ps);
+    const p16x4 k4 = *reinterpret_cast<const p16x4*>(row + pc * qkv_ps + inner);
+    const p16x4 v4 = *reinterpret_cast<const p16x4*>(row + pc * qkv_ps + 2 * inner);
+    *reinterpret_cast<p16x4*>(kcache + pc * cache_ps + ((size_t)t * R + r) * inner + 4 * i) = k4;
+    *reinterpret_cast<p16x4*>(vcache + pc * cache_ps + ((size_t)t * R + r) * inner + 4 * i) = v4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       qf[e] += (float)q4[e];
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restri
     int a[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) a[u] = anc[(size_t)min(j0 + u, t - 1) * R + r];
-    bf16x4 kk[U][S], vv[U][S];
+    p16x4 kk[U][S], vv[U][S];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t off = ((size_t)min(j0 + u, t - 1) * R + a[u]) * inner + 4 * i;
@@ -713,14 +713,14 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const bf16* __restri
   for (int e = 0; e < 4; ++e) acc[e] *= inv;
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) {
-    bf16x4 o;
+    p16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o[e] = (bf16)acc[e];
+      o[e] = (p16)acc[e];
       acc[e] -= (float)o[e];
     }
     // (S == 2: interleaved rows [2 * inner], the O GEMM's A operand)
-    *reinterpret_cast<bf16x4*>(out + (size_t)rc * inner * S + (S == 2 ? inter_off(4 * i, pc) : 4 * i)) = o;
+    *reinterpret_cast<p16x4*>(out + (size_t)rc * inner * S + (S == 2 ? inter_off(4 * i, pc) : 4 * i)) = o;
   }
 }
 
@@ -771,11 +771,11 @@ extern "C" int gram_dec_self_attn_split(const void* qkv, void* kcache, void* vca
   gram_prof::Scope prof(GRAM_K_DEC_SELF_ATTN, st, 4.0 * n_rows * H * 64 * (t + 1) * pieces);
   const dim3 grid(n_rows), block(H * 16);
   if (pieces == 2)
-    hipLaunchKernelGGL(dec_self_attn_kernel<2>, grid, block, 0, st, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, anc, bias,
-                       (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride);
+    hipLaunchKernelGGL(dec_self_attn_kernel<2>, grid, block, 0, st, (const p16*)qkv, (p16*)kcache, (p16*)vcache, anc, bias,
+                       (p16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride);
   else
-    hipLaunchKernelGGL(dec_self_attn_kernel<1>, grid, block, 0, st, (const bf16*)qkv, (bf16*)kcache, (bf16*)vcache, anc, bias,
-                       (bf16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride);
+    hipLaunchKernelGGL(dec_self_attn_kernel<1>, grid, block, 0, st, (const p16*)qkv, (p16*)kcache, (p16*)vcache, anc, bias,
+                       (p16*)out, R, H, t, rows, (long)qkv_pstride, (long)cache_pstride);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

@@ -27,8 +27,8 @@ __device__ __forceinline__ int kswz(int row, int chunk) { return row * 128 + ((c
 __device__ __forceinline__ int vtswz(int d, int key) { return d * 256 + ((((key >> 3) ^ (d & 15))) << 4) + (key & 7) * 2; }
 
 template <int NKS, int S>  // L = 32 * NKS; S = 16-bit pieces per value (1: plain; 2: gram_split_t -- q|k|v planar, the output interleaved)
-__global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ qkv, const float* __restrict__ bias,
-                                                       const uint8_t* __restrict__ mask, bf16* __restrict__ out, int H,
+__global__ __launch_bounds__(256) void enc_attn_kernel(const p16* __restrict__ qkv, const float* __restrict__ bias,
+                                                       const uint8_t* __restrict__ mask, p16* __restrict__ out, int H,
                                                        long qkv_pstride) {
   constexpr int L = 32 * NKS;
   using T = SplitTab<S>;
@@ -45,17 +45,17 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int inner = H * 64;
   const size_t rs = (size_t)3 * inner;  // qkv row stride (elements)
-  const bf16* base = qkv + (size_t)p * L * rs + h * 64;
+  const p16* base = qkv + (size_t)p * L * rs + h * 64;
 
   // K and V rows -> LDS: all 2*NKS 16-byte loads of a thread go out first (written as load; store per iteration,
   // hipcc waits for each pair before issuing the next: NKS exposed HBM round trips per workgroup)
 #pragma unroll
   for (int pc = 0; pc < S; ++pc) {
-    bf16x8 kv[NKS], vv[NKS];
+    p16x8 kv[NKS], vv[NKS];
 #pragma unroll
     for (int it = 0; it < NKS; ++it) {
       const int i = tid + it * 256, row = i >> 3, c = i & 7;
-      const bf16* src = base + pc * qkv_pstride + (size_t)row * rs + c * 8;
+      const p16* src = base + pc * qkv_pstride + (size_t)row * rs + c * 8;
       if constexpr ((GRAM_ENC_ABL & 8) != 0) {
         kv[it] = zero_bf16x8();
         vv[it] = zero_bf16x8();
@@ -68,12 +68,12 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
 #pragma unroll
     for (int it = 0; it < NKS; ++it) {
       const int i = tid + it * 256, row = i >> 3, c = i & 7;
-      *reinterpret_cast<bf16x8*>(ks + pc * 128 * 128 + kswz(row, c)) = kv[it];
+      *reinterpret_cast<p16x8*>(ks + pc * 128 * 128 + kswz(row, c)) = kv[it];
       if constexpr ((GRAM_ENC_ABL & 16) != 0) {
-        *reinterpret_cast<bf16x8*>(vts + pc * 64 * 256 + kswz(row, c)) = vv[it];  // (same bytes, one 16-B store, wrong layout)
+        *reinterpret_cast<p16x8*>(vts + pc * 64 * 256 + kswz(row, c)) = vv[it];  // (same bytes, one 16-B store, wrong layout)
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(vts + pc * 64 * 256 + vtswz(c * 8 + e, row)) = vv[it][e];
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<p16*>(vts + pc * 64 * 256 + vtswz(c * 8 + e, row)) = vv[it][e];
       }
     }
   }
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
   if (q0 >= L) return;
   const int c = lane & 15, g = lane >> 4;
 
-  bf16x8 qf[S][2][2];
+  p16x8 qf[S][2][2];
 #pragma unroll
   for (int pc = 0; pc < S; ++pc)
 #pragma unroll
@@ -114,11 +114,11 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int key = 32 * k2 + 8 * (c >> 2) + 4 * t + (c & 3);  // row permutation (see header)
-      bf16x8 kf[S][2];
+      p16x8 kf[S][2];
 #pragma unroll
       for (int pc = 0; pc < S; ++pc) {
-        kf[pc][0] = *reinterpret_cast<const bf16x8*>(ks + pc * 128 * 128 + kswz(key, g));
-        kf[pc][1] = *reinterpret_cast<const bf16x8*>(ks + pc * 128 * 128 + kswz(key, 4 + g));
+        kf[pc][0] = *reinterpret_cast<const p16x8*>(ks + pc * 128 * 128 + kswz(key, g));
+        kf[pc][1] = *reinterpret_cast<const p16x8*>(ks + pc * 128 * 128 + kswz(key, 4 + g));
       }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
     for (int nt = 0; nt < 2; ++nt) o[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k2 = 0; k2 < NKS; ++k2) {
-    bf16x8 pf[S][2];
+    p16x8 pf[S][2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       if constexpr ((GRAM_ENC_ABL & 2) != 0) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
           for (int j = 0; j < 4; ++j) t += s[k2][tt][nt][j];
         l[nt] += t;
         const uint32_t wv = __float_as_uint(t) & 0x3c003c00u;
-        pf[0][nt] = __builtin_bit_cast(bf16x8, make_uint4(wv, wv, wv, wv));
+        pf[0][nt] = __builtin_bit_cast(p16x8, make_uint4(wv, wv, wv, wv));
         if constexpr (S == 2) pf[S - 1][nt] = pf[0][nt];
       } else if constexpr (S == 2) {  // both pieces of a pair of probabilities at once (split2_pair: 4 vector instructions per pair)
         uint32_t w[2][4];
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
             l[nt] += e1;
             split2_pair(e0, e1, w[0][2 * t + (j >> 1)], w[1][2 * t + (j >> 1)]);
           }
-        pf[0][nt] = __builtin_bit_cast(bf16x8, make_uint4(w[0][0], w[0][1], w[0][2], w[0][3]));
-        pf[1][nt] = __builtin_bit_cast(bf16x8, make_uint4(w[1][0], w[1][1], w[1][2], w[1][3]));
+        pf[0][nt] = __builtin_bit_cast(p16x8, make_uint4(w[0][0], w[0][1], w[0][2], w[0][3]));
+        pf[1][nt] = __builtin_bit_cast(p16x8, make_uint4(w[1][0], w[1][1], w[1][2], w[1][3]));
       } else {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -203,16 +203,16 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
           for (int j = 0; j < 4; ++j) {
             const float e = __expf(s[k2][t][nt][j] - mxq[nt]);
             l[nt] += e;
-            pf[0][nt][4 * t + j] = (bf16)e;
+            pf[0][nt][4 * t + j] = (p16)e;
           }
       }
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const int d = 16 * mt + c;
-      bf16x8 vf[S];
+      p16x8 vf[S];
 #pragma unroll
-      for (int pc = 0; pc < S; ++pc) vf[pc] = *reinterpret_cast<const bf16x8*>(vts + pc * 64 * 256 + vtswz(d, 32 * k2 + 8 * g));
+      for (int pc = 0; pc < S; ++pc) vf[pc] = *reinterpret_cast<const p16x8*>(vts + pc * 64 * 256 + vtswz(d, 32 * k2 + 8 * g));
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
     lt += __shfl_xor(lt, 32, 64);
     const float inv_l = 1.f / lt;
     const int query = q0 + 16 * nt + c;
-    bf16* orow = out + ((size_t)p * L + query) * inner * S;  // (S == 2: the O GEMM's interleaved A operand, [rows][2 * inner])
+    p16* orow = out + ((size_t)p * L + query) * inner * S;  // (S == 2: the O GEMM's interleaved A operand, [rows][2 * inner])
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const f32x4 v = o[mt][nt] * inv_l;
@@ -243,10 +243,10 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const bf16* __restrict__ 
           *reinterpret_cast<uint2*>(orow + inter_off(n, 1)) = lo;
         }
       } else {
-        bf16x4 r;
+        p16x4 r;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = (bf16)v[j];
-        *reinterpret_cast<bf16x4*>(orow + n) = r;
+        for (int j = 0; j < 4; ++j) r[j] = (p16)v[j];
+        *reinterpret_cast<p16x4*>(orow + n) = r;
       }
     }
   }
@@ -267,10 +267,10 @@ int launch_enc(const void* qkv, const float* bias, const uint8_t* mask, void* ou
     attr_set = true;
   }
   switch (L / 32) {
-    case 1: hipLaunchKernelGGL((enc_attn_kernel<1, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride); break;
-    case 2: hipLaunchKernelGGL((enc_attn_kernel<2, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride); break;
-    case 3: hipLaunchKernelGGL((enc_attn_kernel<3, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride); break;
-    default: hipLaunchKernelGGL((enc_attn_kernel<4, S>), grid, block, smem, st, (const bf16*)qkv, bias, mask, (bf16*)out, H, qkv_pstride); break;
+    case 1: hipLaunchKernelGGL((enc_attn_kernel<1, S>), grid, block, smem, st, (const p16*)qkv, bias, mask, (p16*)out, H, qkv_pstride); break;
+    case 2: hipLaunchKernelGGL((enc_attn_kernel<2, S>), grid, block, smem, st, (const p16*)qkv, bias, mask, (p16*)out, H, qkv_pstride); break;
+    case 3: hipLaunchKernelGGL((enc_attn_kernel<3, S>), grid, block, smem, st, (const p16*)qkv, bias, mask, (p16*)out, H, qkv_pstride); break;
+    default: hipLaunchKernelGGL((enc_attn_kernel<4, S>), grid, block, smem, st, (const p16*)qkv, bias, mask, (p16*)out, H, qkv_pstride); break;
   }
   GRAM_CHECK_LAUNCH();
   return 0;

@@ -56,8 +56,10 @@ namespace {
 #ifndef GRAM_PP_INSL
 #define GRAM_PP_INSL 0  // A/B build hook: 1 = two-piece 16-bit outputs from inside the pipeline (measured: no gain, profiles/r03h, r03i)
 #endif
-// In-kernel clock of the ping-pong GEMM (MI355X_MICROARCH.md, DVFS item 6): every workgroup stamps s_memtime (shader cycles) and
-// s_memrealtime (100-MHz ticks) around its tile loop and adds the two differences to these sums -- two atomics per workgroup and launch.
+// In-kernel clock of the ping-pong GEMM (MI355X_MICROARCH.md, DVFS item 6) -- a DIAGNOSTIC, off unless gram_prof_pp_clock_enable(1)
+// (bench.py switches it on for its timed region): every workgroup then stamps s_memtime (shader cycles) and s_memrealtime (100-MHz
+// ticks) around its tile loop and adds the two differences to these sums -- two atomics per workgroup and launch; switched off, the
+// kernel takes one wave-uniform branch around each.
 // gram_prof_pp_clock() = sum / sum x 0.1 GHz: the time-weighted clock the chip held inside these kernels since the last reset (the MFMA
 // peak it can be priced against: the chip is power-limited in them).
 __device__ unsigned long long g_pp_clk[2];
@@ -66,6 +68,7 @@ constexpr int BN = 128, BK = 64;
 enum { V_DMA_M64 = 31, V_DMA = 1, V_DMA_M256 = 3, V_PP = 22, V_RING_M64 = 33, V_RING_M128 = 34 };  // (ids kept from the variant table of round 1)
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
 int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain)
+int g_pp_clk_on = 0;       // gram_prof_pp_clock_enable: the ping-pong kernel's clock stamps (diagnostic; the product path runs without)
 
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -76,7 +79,7 @@ struct EpiArgs {
   float* lse_part;  // GRAM_EPI_F32_LSE: [M][N/64][2]
   int lse_nblk;
   // T5LayerNorm folding (gram_norm_fusion_t)
-  bf16* xb_out;        // producer: bf16 copy of the updated residual
+  p16* xb_out;        // producer: bf16 copy of the updated residual
   float* ss_out;       // producer: [M][N/64] partial sums of squares
   const float* ss_in;  // consumer: [M][ss_nblk] partials of A's rows
   int ss_nblk, ss_out_nblk;
@@ -86,8 +89,8 @@ struct EpiArgs {
   const float* xs_in;  // producer: xb = pieces(x * xs_in[m]); consumer: the row scale is divided by it
   float* xs_out;       // consumer: the first n-tile's workgroups write the next producer's factor
   // KV bank
-  bf16* bank_k;
-  bf16* bank_vt;
+  p16* bank_k;
+  p16* bank_vt;
   int S, H, B, inner;
   const int32_t* pmap;  // compacted encoder rows: passage p = m / pL is flat passage pmap[p] = b*pN + n (NULL: identity)
   int pL, pN;
@@ -145,15 +148,15 @@ __device__ __forceinline__ void compute_tile(const char* sa, const char* sw, int
     // a0*w1, a1*w0, a0*w0 -- smallest first -- from ONE fetch of the four fragment sets
     // (the A fragments of both pieces stay in registers, the W fragments come one n-tile at a time: 10 fragments live, not 16 --
     // the single-stage instantiations run at 128 registers per lane; an accumulator meets its three products 4 MFMAs apart)
-    bf16x8 fa0[4], fa1[4];
+    p16x8 fa0[4], fa1[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + r16, g));
+    for (int i = 0; i < 4; ++i) fa0[i] = *reinterpret_cast<const p16x8*>(sa + swz(wm * 64 + i * 16 + r16, g));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa1[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + r16, 4 + g));
+    for (int i = 0; i < 4; ++i) fa1[i] = *reinterpret_cast<const p16x8*>(sa + swz(wm * 64 + i * 16 + r16, 4 + g));
 #pragma unroll
     for (int i = 0; i < TNW; ++i) {
-      const bf16x8 fw1 = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 16 * TNW + i * 16 + r16, 4 + g));
-      const bf16x8 fw0 = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 16 * TNW + i * 16 + r16, g));
+      const p16x8 fw1 = *reinterpret_cast<const p16x8*>(sw + swz(wn * 16 * TNW + i * 16 + r16, 4 + g));
+      const p16x8 fw0 = *reinterpret_cast<const p16x8*>(sw + swz(wn * 16 * TNW + i * 16 + r16, g));
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(fw1, fa0[j], acc[i][j]);
 #pragma unroll
@@ -165,11 +168,11 @@ __device__ __forceinline__ void compute_tile(const char* sa, const char* sw, int
   }
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 fw[TNW], fa[4];
+    p16x8 fw[TNW], fa[4];
 #pragma unroll
-    for (int i = 0; i < TNW; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 16 * TNW + i * 16 + r16, ks * 4 + g));
+    for (int i = 0; i < TNW; ++i) fw[i] = *reinterpret_cast<const p16x8*>(sw + swz(wn * 16 * TNW + i * 16 + r16, ks * 4 + g));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + r16, ks * 4 + g));
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const p16x8*>(sa + swz(wm * 64 + i * 16 + r16, ks * 4 + g));
 #pragma unroll
     for (int i = 0; i < TNW; ++i)
 #pragma unroll
@@ -223,15 +226,15 @@ __device__ __forceinline__ void load_row_scales(const EpiArgs& ep, int mbase, in
 }
 
 __device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
-  bf16x4 o;
+  p16x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+  for (int e = 0; e < 4; ++e) o[e] = (p16)v[e];
   return __builtin_bit_cast(uint2, o);
 }
 __device__ __forceinline__ f32x4 unpack_bf16x4(uint2 u) {
   f32x4 r;
 #ifdef GRAM_F16
-  const bf16x4 h = __builtin_bit_cast(bf16x4, u);
+  const p16x4 h = __builtin_bit_cast(p16x4, u);
 #pragma unroll
   for (int e = 0; e < 4; ++e) r[e] = (float)h[e];
 #else
@@ -272,7 +275,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
           recv.y = __shfl_xor(send.y, 16, 64);
           // even g: tile i, columns 8*(g/2)..+7 = [own lo | partner's lo]; odd g: tile i+1 = [partner's hi | own hi]
           const uint4 out = odd ? make_uint4(recv.x, recv.y, hi.x, hi.y) : make_uint4(lo.x, lo.y, recv.x, recv.y);
-          bf16* dst = reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + (ep.c_inter ? inter_off(n, pc) : pc * ep.c_pstride + n);
+          p16* dst = reinterpret_cast<p16*>(ep.C) + (size_t)m * ep.ldc + (ep.c_inter ? inter_off(n, pc) : pc * ep.c_pstride + n);
           if (row_ok) *reinterpret_cast<uint4*>(dst) = out;
           if (pc + 1 < ep.split) {
             v0 -= unpack_bf16x4(lo);
@@ -330,7 +333,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
           *p = nv;
           if (ep.xb_out) {
             f32x4 rem = ep.xs_in ? nv * ep.xs_in[m] : nv;
-            bf16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
+            p16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
             for (int pc = 0; pc < ep.split; ++pc) {
               const uint2 pk = pack_bf16x4(rem);
               *reinterpret_cast<uint2*>(xrow + (ep.split == 2 ? inter_off(n, pc) : n)) = pk;
@@ -360,7 +363,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[TNW][4], int m0, int n0, i
             if (which == 0) {
               *reinterpret_cast<uint2*>(ep.bank_k + pc * ep.bank_pstride + (head * ep.S + s) * 64 + d) = o;
             } else {
-              const bf16x4 ob = __builtin_bit_cast(bf16x4, o);
+              const p16x4 ob = __builtin_bit_cast(p16x4, o);
 #pragma unroll
               for (int e = 0; e < 4; ++e)  // V^T blocked by 32 keys: [head][s / 32][64 d][32]
                 ep.bank_vt[pc * ep.bank_pstride + ((head * (ep.S >> 5) + (s >> 5)) * 64 + d + e) * 32 + (s & 31)] = ob[e];
@@ -420,7 +423,7 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
         if constexpr (EPI == GRAM_EPI_F32_ADD) {
           if (ep.xb_out) {
             f32x4 rem = ep.xs_in ? val * ep.xs_in[m] : val;
-            bf16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
+            p16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
             const int n = n0 + wn * 64 + c * 4;
             for (int pc = 0; pc < ep.split; ++pc) {
               const uint2 pk = pack_bf16x4(rem);
@@ -459,14 +462,14 @@ __device__ __forceinline__ void epilogue_rows64(f32x4 (&acc)[4][4], char* patch 
 // wave 0 runs the common epilogue on the 64 x 64 tile, so every output bit equals the tiled kernels' (same MFMA
 // sequence per accumulator, same epilogue code).
 template <int EPI, int MT, bool X3>  // MT = m-tiles of 16 rows per workgroup that exist (M <= 16 * MT, or MT = 4 and a grid row per 64 rows)
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const p16* __restrict__ A, const p16* __restrict__ W, int M, int N,
                                                           int K, int lda, EpiArgs ep) {
   __shared__ f32x4 xch[4][MT][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
-  const bf16* wp = W + (size_t)(n0 + wave * 16 + r16) * K + g * 8;
-  const bf16* ap[MT];
+  const p16* wp = W + (size_t)(n0 + wave * 16 + r16) * K + g * 8;
+  const p16* ap[MT];
   bool a_ok[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
   constexpr int U = 8;
   const int nkb = K >> 5;  // physical 32-column k-blocks (X3: an even/odd pair = piece 0 / piece 1 of one block of K)
   for (int kb = 0; kb < nkb; kb += U) {
-    bf16x8 fw[U], fa[U][MT];
+    p16x8 fw[U], fa[U][MT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = min(kb + u, nkb - 1) << 5;  // (past the end: a valid re-read, not used)
@@ -534,9 +537,9 @@ template <int EPI, bool X3>
 int launch_skinny(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
   if (M < 1 || N % 64 || K % (X3 ? 64 : 32) || (M + 63) / 64 > 65535) return GRAM_E_ARG;
   const dim3 grid(N / 64, (M + 63) / 64), block(256);
-  if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1, X3>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
-  else if (M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2, X3>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
-  else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4, X3>), grid, block, 0, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, ep);
+  if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 1, X3>), grid, block, 0, st, (const p16*)A, (const p16*)W, M, N, K, lda, ep);
+  else if (M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 2, X3>), grid, block, 0, st, (const p16*)A, (const p16*)W, M, N, K, lda, ep);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<EPI, 4, X3>), grid, block, 0, st, (const p16*)A, (const p16*)W, M, N, K, lda, ep);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -630,7 +633,7 @@ __device__ __forceinline__ float row_rscale_stream(const EpiArgs& ep, int m, flo
 }
 
 template <int EPI, int MT, bool X3>
-__global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
+__global__ __launch_bounds__(256) void gemm_stream_kernel(const p16* __restrict__ A, const p16* __restrict__ W, int M, int N,
                                                           int K, int lda, int G, EpiArgs ep) {
   static_assert(EPI == GRAM_EPI_BF16 || EPI == GRAM_EPI_BF16_RELU || EPI == GRAM_EPI_F32_ADD, "stream kernel epilogues");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -687,19 +690,19 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) foff[kb] = r16 * 256 + (((kb * 4 + g) ^ r16) << 4);
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 fw0[4], fa0[4], fw1[4], fa1[4];  // fragments of the stage being read and of the one being multiplied (one stage behind)
+  p16x8 fw0[4], fa0[4], fw1[4], fa1[4];  // fragments of the stage being read and of the one being multiplied (one stage behind)
   int c_slot = 0;
-  auto read_frags = [&](bf16x8 (&fw)[4], bf16x8 (&fa)[4]) {
+  auto read_frags = [&](p16x8 (&fw)[4], p16x8 (&fa)[4]) {
     const char* sw = smem + c_slot * SB;
     const char* sa = sw + 4096 * (1 + wave);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      fw[kb] = *reinterpret_cast<const bf16x8*>(sw + foff[kb]);
-      fa[kb] = *reinterpret_cast<const bf16x8*>(sa + foff[kb]);
+      fw[kb] = *reinterpret_cast<const p16x8*>(sw + foff[kb]);
+      fa[kb] = *reinterpret_cast<const p16x8*>(sa + foff[kb]);
     }
     c_slot = c_slot + 1 == NS ? 0 : c_slot + 1;
   };
-  auto mfmas = [&](const bf16x8 (&fw)[4], const bf16x8 (&fa)[4]) {
+  auto mfmas = [&](const p16x8 (&fw)[4], const p16x8 (&fa)[4]) {
     if constexpr (X3) {
 #pragma unroll
       for (int kb = 0; kb < 4; kb += 2) {  // k-blocks (kb, kb + 1) = the two pieces of one block of K: a0*w1, a1*w0, a0*w0
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
   };
   // Stage st: wait for this wave's part of it, barrier (everyone's part has landed; stage st - 1 has been read: the barrier's
   // lgkmcnt(0)), read its fragments, refill the slot of stage st - 1, multiply stage st - 1 while the reads are in flight.
-  auto step = [&](int st, bool steady, bf16x8 (&cw)[4], bf16x8 (&ca)[4], const bf16x8 (&pw)[4], const bf16x8 (&pa)[4]) {
+  auto step = [&](int st, bool steady, p16x8 (&cw)[4], p16x8 (&ca)[4], const p16x8 (&pw)[4], const p16x8 (&pa)[4]) {
     if (steady) wait_vmcnt<(Q * (NS - 2) <= 63 ? Q * (NS - 2) : 63)>();
     else wait_later<Q>(nst - 1 - st);
     __syncthreads();
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
       *pc = val;
       if (ep.xb_out) {
         f32x4 rem = ep.xs_in ? val * ep.xs_in[m] : val;
-        bf16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
+        p16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
         for (int p = 0; p < ep.split; ++p) {
           const uint2 pk = pack_bf16x4(rem);
           *reinterpret_cast<uint2*>(xrow + (ep.split == 2 ? inter_off(n, p) : n)) = pk;
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const bf16* __restrict
     for (int p = 0; p < ep.split; ++p) {
       const uint2 pk = pack_bf16x4(v);
       if (row_ok)
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(ep.C) + (size_t)m * ep.ldc + (ep.c_inter ? inter_off(n, p) : p * ep.c_pstride + n)) = pk;
+        *reinterpret_cast<uint2*>(reinterpret_cast<p16*>(ep.C) + (size_t)m * ep.ldc + (ep.c_inter ? inter_off(n, p) : p * ep.c_pstride + n)) = pk;
       if (p + 1 < ep.split) v -= unpack_bf16x4(pk);
     }
   }
@@ -797,7 +800,7 @@ int launch_stream_mt(const void* A, const void* W, int M, int N, int K, int lda,
     attr_set = true;
   }
   const int G = (M + 16 * MT - 1) / (16 * MT);
-  hipLaunchKernelGGL((gemm_stream_kernel<EPI, MT, X3>), dim3((N / 16) * G), dim3(256), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda, G, ep);
+  hipLaunchKernelGGL((gemm_stream_kernel<EPI, MT, X3>), dim3((N / 16) * G), dim3(256), smem, st, (const p16*)A, (const p16*)W, M, N, K, lda, G, ep);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -815,7 +818,7 @@ int launch_stream(const void* A, const void* W, int M, int N, int K, int lda, Ep
 // ---------------------------------------------------------------------------------------------
 template <int EPI, int WM, int NST, int TNW, bool X3>
 __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 ? (X3 ? 3 : 4) : 2))) void gemm_dma_kernel(
-    const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N, int K, int lda, EpiArgs ep) {
+    const p16* __restrict__ A, const p16* __restrict__ W, int M, int N, int K, int lda, EpiArgs ep) {
   // WM x 2 waves, block tile (64*WM) x 128.  NST = 1: single LDS stage, latency hidden by the other
   // resident workgroups.  NST = 2: the DMA of k-tile kt+1 is issued before the MFMAs of k-tile kt and
   // drained by the (single) barrier after them.
@@ -835,8 +838,8 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
   // LDS-DMA map: a wave instruction fills one 8-row x 128-B group (1 KiB, lane-linear).
   // Lane l lands at (row 8*grp + l>>3, slot l&7), so it must FETCH chunk (l&7) ^ ((row>>1)&7)
   // for the read-side swizzle to find it.
-  const bf16* a_src[AG];
-  const bf16* w_src[WG];
+  const p16* a_src[AG];
+  const p16* w_src[WG];
 #pragma unroll
   for (int i = 0; i < AG; ++i) {
     const int row = (wave * AG + i) * 8 + (lane >> 3);
@@ -1187,7 +1190,7 @@ __device__ __forceinline__ void pp_store_rows(f32x4 (&acc)[4][8], int j0, char* 
 }
 
 template <int EPI, bool X3 = false>
-__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
+__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const p16* __restrict__ A, const p16* __restrict__ W, int M, int N,
                                                          int K, int lda, EpiArgs ep, int ntiles, int stagger) {
   constexpr int TB = 256, HT = 16384;
   constexpr bool F32OUT = EPI == GRAM_EPI_F32 || EPI == GRAM_EPI_F32_ADD;
@@ -1241,7 +1244,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
 
   // tile index -> (m-tile, n-tile column).  gm <= 1: n fastest.  gm > 1: groups of gm m-tiles, m fastest inside a group, so
   // that the 32 tiles an XCD works on at a time cover gm m-tiles x 32/gm n-tiles (fewer distinct A + W panels per round).
-  const int gm = stagger >> 16;
+  const int gm = (stagger >> 16) & 0xff;
+  const bool clk_on = (stagger >> 30) & 1;  // (gram_prof_pp_clock_enable)
   stagger &= 0xffff;
   auto decode = [&](int tile, int& mt, int& nr) {
     if (gm <= 1) {
@@ -1323,7 +1327,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   };
 
   f32x4 acc[4][8];
-  bf16x8 fa[2][4], fw[2][2][2];
+  p16x8 fa[2][4], fw[2][2][2];
   // fragment addresses: one per-lane base per operand and k-step; the m-/n-tile (16 rows = 2 KiB: the swizzle term
   // (row >> 1) & 7 does not change) and the buffer are immediate offsets
   const char* const a_base[2] = {smem + swz(wr * 64 + r16, g), smem + swz(wr * 64 + r16, 4 + g)};
@@ -1335,7 +1339,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          fa[ks][j] = *reinterpret_cast<const bf16x8*>(a_base[ks] + (par * 4 + (mq ? 3 : 0)) * HT + j * 2048);
+          fa[ks][j] = *reinterpret_cast<const p16x8*>(a_base[ks] + (par * 4 + (mq ? 3 : 0)) * HT + j * 2048);
     }
   };
   auto read_w = [&](int par, int nq) {
@@ -1345,7 +1349,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          fw[nq][ks][i] = *reinterpret_cast<const bf16x8*>(w_base[ks] + (par * 4 + 1 + nq) * HT + i * 2048);
+          fw[nq][ks][i] = *reinterpret_cast<const p16x8*>(w_base[ks] + (par * 4 + 1 + nq) * HT + i * 2048);
     }
   };
   // TR (KV bank, V^T half): operands the other way round, so a lane ends up with 4 consecutive ROWS (bank
@@ -1781,9 +1785,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
   zero_half(0);
   zero_half(1);
   abl_loop = true;
-#ifndef GRAM_PP_NOCLK  // (A/B build hook: the kernel without its two clock stamps)
-  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  unsigned long long clk_t0 = 0ull, clk_r0 = 0ull;
+  if (clk_on) {
+    clk_t0 = __builtin_amdgcn_s_memtime();
+    clk_r0 = __builtin_amdgcn_s_memrealtime();
+  }
   if constexpr (INSL) {
     const float *rs_cur = nullptr, *rs_prev = nullptr;
     auto set_tile = [&]() {
@@ -2121,12 +2127,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const bf16* __restrict_
     tile += G;
   }
   }
-#ifndef GRAM_PP_NOCLK
-  if (tid == 0) {
+  if (clk_on && tid == 0) {
     atomicAdd(&g_pp_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk_t0);
     atomicAdd(&g_pp_clk[1], (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0);
   }
-#endif
   // The last tile's m1 half is still in the accumulators.  Every DMA of this workgroup must have landed before it
   // ends, and after that the half-tile buffers are dead: they serve as 8 private patches for the final stores.
   if constexpr (!TEND) {
@@ -2213,8 +2217,8 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     static const int stagger_env = getenv("GRAM_GEMM_STAGGER") ? atoi(getenv("GRAM_GEMM_STAGGER")) : -1;
     static const int stagger_xcd = getenv("GRAM_GEMM_STAGGER_XCD") ? atoi(getenv("GRAM_GEMM_STAGGER_XCD")) : 0;  // phase = XCD instead of slot & 7
     const int stagger = (stagger_env >= 0 ? stagger_env : g_stagger) | (stagger_xcd ? 0x8000 : 0);
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, X3>), dim3(nblocks), dim3(512), smem, st, (const bf16*)A, (const bf16*)W, M, N, K, lda,
-                       ep, ntiles, (stagger & 0xffff) | (gm << 16));
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, X3>), dim3(nblocks), dim3(512), smem, st, (const p16*)A, (const p16*)W, M, N, K, lda,
+                       ep, ntiles, (stagger & 0xffff) | (gm << 16) | (g_pp_clk_on ? 1 << 30 : 0));
     GRAM_CHECK_LAUNCH();
     return 0;
   }
@@ -2266,7 +2270,7 @@ int launch_dma(const void* A, const void* W, int M, int N, int K, int lda, EpiAr
   }
   static const int rows_env = getenv("GRAM_GEMM_DMAROWS") ? atoi(getenv("GRAM_GEMM_DMAROWS")) : 1;  // A/B hook; measured +1.2 % end to end
   if (rows_env) ep.nt |= 4;
-  hipLaunchKernelGGL((gemm_dma_kernel<EPI, WM, NST, TNW, X3>), dim3(nblocks), dim3(WM * 128), smem, st, (const bf16*)A, (const bf16*)W,
+  hipLaunchKernelGGL((gemm_dma_kernel<EPI, WM, NST, TNW, X3>), dim3(nblocks), dim3(WM * 128), smem, st, (const p16*)A, (const p16*)W,
                      M, N, K, lda, ep);
   GRAM_CHECK_LAUNCH();
   return 0;
@@ -2330,6 +2334,11 @@ int launch(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs e
 }
 
 }  // namespace
+
+extern "C" int gram_prof_pp_clock_enable(int on) {
+  g_pp_clk_on = on != 0;
+  return 0;
+}
 
 extern "C" int gram_prof_pp_clock(double* ghz, int reset) {
   unsigned long long h[2] = {0ull, 0ull};
@@ -2424,7 +2433,7 @@ extern "C" int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M
   if (nf) {
     if (epilogue == GRAM_EPI_F32_ADD) {
       if ((nf->xb_out == nullptr) != (nf->ss_out == nullptr)) return GRAM_E_ARG;
-      ep.xb_out = (bf16*)nf->xb_out;
+      ep.xb_out = (p16*)nf->xb_out;
       ep.ss_out = nf->ss_out;
       ep.ss_quarter = nf->quarter != 0 && nf->ss_out;
       ep.ss_out_nblk = ep.ss_quarter ? N / 16 : N / 64;
@@ -2465,8 +2474,8 @@ extern "C" int gram_gemm_bf16_split(const void* A, const void* W, void* C, int M
       } else if (M != bank->B * bank->S) {
         return GRAM_E_ARG;
       }
-      ep.bank_k = (bf16*)bank->k;
-      ep.bank_vt = (bf16*)bank->vt;
+      ep.bank_k = (p16*)bank->k;
+      ep.bank_vt = (p16*)bank->vt;
       ep.S = bank->S;
       ep.H = bank->H;
       ep.B = bank->B;

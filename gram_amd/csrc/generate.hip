@@ -15,23 +15,7 @@
 #include "common.h"
 #include "prof.h"
 
-// A captured generate(): the launch train of one problem shape as a HIP graph (small batches are a chain of ~1 000 dependent
-// launches; replaying them from a graph removes the per-launch host cost).  Everything the graph touches lives in the
-// workspace (inputs and results are staged there), so an entry stays valid as long as the workspace and the Trie do.
-struct GraphEntry {
-  int B, N, L, K, nret, Tmax;
-  float lp;
-  const void *ws, *t_off, *t_tok, *t_node;
-  int t_nodes, t_edges, t_fan, t_min;
-  hipGraphExec_t exec;  // nullptr: shape seen once (run eagerly -- the SAME launch train the capture records, live-row compaction
-                        // off -- so that every lazy one-time initialisation of those kernels has happened outside the capture)
-  bool failed;          // a capture / instantiation failed once: this shape stays on eager launches
-};
-
 struct gram_model {
-  std::vector<GraphEntry> graphs;
-  hipStream_t cap_stream = nullptr;  // launches are recorded on a private stream (PyTorch's default stream is the legacy null
-                                     // stream, which cannot capture); the graph is then replayed on the caller's stream
   gram_model_desc_t d;
   std::vector<const float*> enc_ln1, enc_ln2, dec_ln1, dec_ln2, dec_ln3;
   std::vector<const void*> enc_wqkv, enc_wo, enc_wi, enc_wo2, dec_wqkv, dec_wo, dec_wq_x, dec_wo_x, dec_wi, dec_wo2;
@@ -55,8 +39,6 @@ struct Carve {
   }
 };
 
-constexpr int64_t kGraphMaxRows = 4096;  // B*K up to which generate() is replayed from a HIP graph (GRAM_GRAPH=0: never)
-
 // The folded-norm partial sums of squares are [rows][d / 64] floats, or -- "quarter" layout of the streaming small-M GEMM, chosen per
 // CALL from the rows that call works on (all of them, the compacted encoder rows, the live rows of a late decode step) --
 // [rows_of_the_call][d / 16] with rows_of_the_call <= gram_gemm_stream_max_m() <= kStreamRowsLimit.  The buffer holds the larger of
@@ -69,28 +51,28 @@ inline int64_t ss_floats(int64_t rows, int64_t d) {
 struct Workspace {
   // encoder
   float* x;         // [Me][d]   residual stream (fp32)
-  bf16* h;          // [Me][d]   normed activations (GEMM A operand)
-  bf16* qkv;        // [Me][3*inner]
-  bf16* attn;       // [Me][inner]
-  bf16* u;          // [Me][d_ff]
+  p16* h;          // [Me][d]   normed activations (GEMM A operand)
+  p16* qkv;        // [Me][3*inner]
+  p16* attn;       // [Me][inner]
+  p16* u;          // [Me][d_ff]
   float* ss;        // [Me][d/64]  folded-norm partial sums of squares
   float* rs;        // [Me]        1/rms per row
   float* xs[2];     // [Me] x 2    per-row power-of-two factors of the 16-bit copy of x (gram_norm_fusion_t.xs_in / xs_out), ping-pong
   // fused bank
-  bf16* bank_k;     // [layers][B][H][S][64]
-  bf16* bank_vt;    // [layers][B][H][S/32][64][32]
+  p16* bank_k;     // [layers][B][H][S][64]
+  p16* bank_vt;    // [layers][B][H][S/32][64][32]
   // decoder
   float* xd;        // [R][d]
-  bf16* hd;         // [R][d]
-  bf16* qkvd;       // [R][3*inner]
-  bf16* attnd;      // [R][inner]
-  bf16* qx;         // [R][inner]
-  bf16* ud;         // [R][d_ff]
+  p16* hd;         // [R][d]
+  p16* qkvd;       // [R][3*inner]
+  p16* attnd;      // [R][inner]
+  p16* qx;         // [R][inner]
+  p16* ud;         // [R][d_ff]
   float* ssd;       // [R][d/64]
   float* rsd;       // [R]
   float* xsd[2];    // [R] x 2
-  bf16* kcache;     // [layers][Tmax][R][inner]
-  bf16* vcache;
+  p16* kcache;     // [layers][Tmax][R][inner]
+  p16* vcache;
   float* logits;    // [R][V]
   float* lse;       // [R]
   float* lse_part;  // [R][V/64][2]
@@ -99,11 +81,6 @@ struct Workspace {
   gram_live_rows_t live;
   int32_t* width;
   uint32_t* key_bits;  // [B][128]  the cross-attention's bit view of the mask (gram_mask_key_bits), once per generate
-  // staging for the graph path: the captured launches read inputs from / write results to the workspace only
-  int64_t* ids_stage;    // [B][N][L]
-  uint8_t* mask_stage;   // [B][N][L]
-  int64_t* seq_stage;    // [B*K][Tmax]
-  float* score_stage;    // [B*K]
   int64_t bytes;
   // two-piece mode (gram_split_t): what a GEMM reads (h, attn, u, hd, attnd, ud) is ONE interleaved buffer of twice the row length;
   // what only attention kernels read (qkv, the bank, qkvd, qx, the cache) is `pieces` planar copies, these many elements apart
@@ -125,28 +102,28 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   w.ps_qx = R * inner;
   w.ps_cache = nl * Tmax * R * inner;
   w.x = cv.take<float>(Me * d);
-  w.h = cv.take<bf16>(P * Me * d);
-  w.qkv = cv.take<bf16>(P * w.ps_qkv);
-  w.attn = cv.take<bf16>(P * Me * inner);
-  w.u = cv.take<bf16>(P * Me * F);
+  w.h = cv.take<p16>(P * Me * d);
+  w.qkv = cv.take<p16>(P * w.ps_qkv);
+  w.attn = cv.take<p16>(P * Me * inner);
+  w.u = cv.take<p16>(P * Me * F);
   w.ss = cv.take<float>(ss_floats(Me, d));
   w.rs = cv.take<float>(Me);
   w.xs[0] = cv.take<float>(Me);
   w.xs[1] = cv.take<float>(Me);
-  w.bank_k = cv.take<bf16>(P * w.ps_bank);
-  w.bank_vt = cv.take<bf16>(P * w.ps_bank);
+  w.bank_k = cv.take<p16>(P * w.ps_bank);
+  w.bank_vt = cv.take<p16>(P * w.ps_bank);
   w.xd = cv.take<float>(R * d);
-  w.hd = cv.take<bf16>(P * R * d);
-  w.qkvd = cv.take<bf16>(P * w.ps_qkvd);
-  w.attnd = cv.take<bf16>(P * R * inner);
-  w.qx = cv.take<bf16>(P * w.ps_qx);
-  w.ud = cv.take<bf16>(P * R * F);
+  w.hd = cv.take<p16>(P * R * d);
+  w.qkvd = cv.take<p16>(P * w.ps_qkvd);
+  w.attnd = cv.take<p16>(P * R * inner);
+  w.qx = cv.take<p16>(P * w.ps_qx);
+  w.ud = cv.take<p16>(P * R * F);
   w.ssd = cv.take<float>(ss_floats(R, d));  // (16-column partials for a small-M step: gram_norm_fusion_t.quarter)
   w.rsd = cv.take<float>(R);
   w.xsd[0] = cv.take<float>(R);
   w.xsd[1] = cv.take<float>(R);
-  w.kcache = cv.take<bf16>(P * w.ps_cache);
-  w.vcache = cv.take<bf16>(P * w.ps_cache);
+  w.kcache = cv.take<p16>(P * w.ps_cache);
+  w.vcache = cv.take<p16>(P * w.ps_cache);
   w.logits = cv.take<float>(R * V);
   w.lse = cv.take<float>(R);
   w.lse_part = cv.take<float>(R * (V / 64) * 2);
@@ -176,12 +153,6 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   w.live.counts = cv.take<int32_t>(4);
   w.width = cv.take<int32_t>(4);
   w.key_bits = cv.take<uint32_t>((int64_t)B * 128);
-  if (R <= kGraphMaxRows) {
-    w.ids_stage = cv.take<int64_t>(Me);
-    w.mask_stage = cv.take<uint8_t>(Me);
-    w.seq_stage = cv.take<int64_t>(R * Tmax);
-    w.score_stage = cv.take<float>(R);
-  }
   w.bytes = (cv.off + 255) & ~(int64_t)255;
   return w;
 }
@@ -209,7 +180,7 @@ int g_stage_cap[GRAM_STAGE_COUNT] = {99, 99, 99, 99, 99, 99, 99, 99};
 // planar buffer: `pieces` copies, ps elements apart
 int cap_planar(const Workspace& w, void* buf, int64_t ps, int stage, void* st) {
   if (w.pieces < 2 || g_stage_cap[stage] >= 2) return 0;
-  hipError_t e = hipMemsetAsync((bf16*)buf + (size_t)ps, 0, (size_t)ps * sizeof(bf16), (hipStream_t)st);
+  hipError_t e = hipMemsetAsync((p16*)buf + (size_t)ps, 0, (size_t)ps * sizeof(p16), (hipStream_t)st);
   return e == hipSuccess ? 0 : (int)e;
 }
 // interleaved buffer [rows][cols / 32][2][32]: piece 1 = the second 64 B of every 128 B
@@ -462,11 +433,6 @@ extern "C" int gram_debug_set_stage_pieces(const int32_t* caps, int n) {
   return 0;
 }
 
-static int g_graph = -1;      // -1: the GRAM_GRAPH environment variable decides (default on)
-extern "C" int gram_debug_set_graph(int on) {
-  g_graph = on;
-  return 0;
-}
 static int g_live_rows = -1;  // -1: the GRAM_LIVE_ROWS environment variable decides (default on)
 extern "C" int gram_debug_set_live_rows(int on) {
   g_live_rows = on;
@@ -543,9 +509,6 @@ extern "C" gram_model_t* gram_model_create(const gram_model_desc_t* d) {
 
 extern "C" void gram_model_destroy(gram_model_t* m) {
   if (!m) return;
-  for (auto& g : m->graphs)
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   delete m;
 }
 
@@ -568,7 +531,7 @@ extern "C" int gram_encode_fused(const gram_model_t* m, const int64_t* input_ids
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
   TRY(encode(m, w, input_ids, mask, mask, B, N, L, B * N, nullptr, CachedPassages{0, 0, nullptr, nullptr}, stream));
   if (enc_out_bf16) {  // (split modes: all the pieces, [pieces][B*N*L][d])
-    hipError_t e = hipMemcpyAsync(enc_out_bf16, w.h, (size_t)w.pieces * B * N * L * m->d.d_model * sizeof(bf16), hipMemcpyDeviceToDevice,  // (interleaved rows)
+    hipError_t e = hipMemcpyAsync(enc_out_bf16, w.h, (size_t)w.pieces * B * N * L * m->d.d_model * sizeof(p16), hipMemcpyDeviceToDevice,  // (interleaved rows)
                                   (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
@@ -605,12 +568,13 @@ extern "C" int gram_generate(const gram_model_t* m, const int64_t* input_ids, co
 }
 
 namespace {
-// encode -> search -> finalize of one generate() on `stream`.  capturing: the launches are being recorded into a HIP graph, so
-// nothing here may synchronise (the live-row compaction, whose row counts travel through the host, is left out; results
-// are bit-identical with and without it).
+// encode -> search -> finalize of one generate() on `stream`.
+// (Replaying a small batch's launch train from a HIP graph was built in round 2 and measured in three rounds -- B = 1: 20.1 vs 20.2 ms,
+// 14.1 vs 12.8 ms, 11.5 vs 10.65 ms eager: the chain is bound by the GPU-side dependency between ~950 tiny kernels, not by the host's
+// launch cost, and a captured train cannot take the live-row step, whose row counts travel through the host -- and removed in round 4.)
 int generate_body(const gram_model* m, Workspace& w, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K, int nret,
                   int max_length, const gram_trie_t* trie, const gram_compaction_t* comp, int64_t* sequences, float* scores,
-                  bool capturing, void* stream) {
+                  void* stream) {
   if (comp)  // the encoder runs on the active passages only; padded ones leave their bank positions untouched (never read)
     TRY(encode(m, w, comp->ids, comp->mask, mask, B, N, L, comp->n_active, comp->passage_map,
                CachedPassages{comp->n_cached, comp->cache_L, comp->cache_x, comp->cache_slot}, stream));
@@ -628,7 +592,7 @@ int generate_body(const gram_model* m, Workspace& w, const int64_t* input_ids, c
     const char* e = getenv("GRAM_LIVE_ROWS");
     return !(e && e[0] == '0');
   }();
-  const bool live_rows = !capturing && (g_live_rows < 0 ? live_rows_env : g_live_rows != 0);  // (the live-row step needs a host round trip)
+  const bool live_rows = g_live_rows < 0 ? live_rows_env : g_live_rows != 0;  // (the live-row step needs a host round trip)
   // fixed max_length-1 steps: finished users are padded exactly as BeamSearchScorer.process
   // pads them, so skipping HF's all-done early exit changes nothing and needs no host sync
   for (int t = 0; t + 1 < max_length; ++t) {
@@ -668,16 +632,6 @@ int generate_body(const gram_model* m, Workspace& w, const int64_t* input_ids, c
   return 0;
 }
 
-// Off unless GRAM_GRAPH=1: measured on MI355X, replaying the ~900 dependent launches of a one-user generate() from a graph
-// takes 20.1 ms against 20.2 ms launched one by one -- the chain is bound by the GPU-side dependency between tiny kernels,
-// not by the host's launch cost (profiles/README.md).
-bool graph_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("GRAM_GRAPH");
-    return e && e[0] == '1';
-  }();
-  return g_graph < 0 ? on : g_graph != 0;
-}
 }  // namespace
 
 extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids, const uint8_t* mask, int B, int N, int L, int K,
@@ -696,71 +650,7 @@ extern "C" int gram_generate_ex(const gram_model_t* m, const int64_t* input_ids,
   Workspace w = carve(m, workspace, B, N, L, K, max_length);
   if (!workspace || workspace_bytes < w.bytes) return GRAM_E_WORKSPACE;
   w.beam.length_penalty = length_penalty;
-  hipStream_t hs = (hipStream_t)stream;
-  // Small batches: replay the launch train from a HIP graph.  Not while per-kernel events are being recorded (bench.py's
-  // profiler), not with a compaction (its arrays are per-call buffers outside the workspace), not for greedy search.
-  const bool graphable = graph_enabled() && !comp && K > 1 && (int64_t)B * K <= kGraphMaxRows && w.ids_stage && gram_prof::g_mask == 0;
-  if (!graphable) {
-    TRY(generate_body(m, w, input_ids, mask, B, N, L, K, nret, max_length, trie, comp, sequences, scores, false, stream));
-  } else {
-    gram_model* mm = const_cast<gram_model*>(m);
-    GraphEntry key{B, N, L, K, nret, max_length, length_penalty, workspace, trie->child_off, trie->child_tok, trie->child_node,
-                   trie->n_nodes, trie->n_edges, trie->max_fanout, trie->min_seq_len, nullptr, false};
-    GraphEntry* hit = nullptr;
-    for (auto& g : mm->graphs)
-      if (g.B == B && g.N == N && g.L == L && g.K == K && g.nret == nret && g.Tmax == max_length && g.lp == length_penalty &&
-          g.ws == workspace && g.t_off == key.t_off && g.t_tok == key.t_tok && g.t_node == key.t_node && g.t_nodes == key.t_nodes &&
-          g.t_edges == key.t_edges && g.t_fan == key.t_fan && g.t_min == key.t_min)
-        hit = &g;
-    const size_t in_elems = (size_t)B * N * L;
-    hipError_t e = hipMemcpyAsync(w.ids_stage, input_ids, in_elems * sizeof(int64_t), hipMemcpyDeviceToDevice, hs);
-    if (e == hipSuccess) e = hipMemcpyAsync(w.mask_stage, mask, in_elems, hipMemcpyDeviceToDevice, hs);
-    if (e != hipSuccess) return (int)e;
-    if (!hit) {  // first sight of this shape: run it eagerly (on the staged buffers) and remember it
-      if (mm->graphs.size() >= 16) {
-        for (auto& g : mm->graphs)
-          if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        mm->graphs.clear();
-      }
-      mm->graphs.push_back(key);
-      // (capturing = true: no live-row compaction, i.e. exactly the kernels and instantiations the capture will launch)
-      TRY(generate_body(m, w, w.ids_stage, w.mask_stage, B, N, L, K, nret, max_length, trie, nullptr, w.seq_stage, w.score_stage, true,
-                        stream));
-    } else if (hit->failed) {
-      TRY(generate_body(m, w, w.ids_stage, w.mask_stage, B, N, L, K, nret, max_length, trie, nullptr, w.seq_stage, w.score_stage, false,
-                        stream));
-    } else {
-      if (!hit->exec) {  // second call: record the launch train
-        hipGraph_t graph = nullptr;
-        if (!mm->cap_stream) {
-          e = hipStreamCreateWithFlags(&mm->cap_stream, hipStreamNonBlocking);
-          if (e != hipSuccess) return (int)e;
-        }
-        e = hipStreamBeginCapture(mm->cap_stream, hipStreamCaptureModeThreadLocal);
-        if (e != hipSuccess) return (int)e;
-        const int rc = generate_body(m, w, w.ids_stage, w.mask_stage, B, N, L, K, nret, max_length, trie, nullptr, w.seq_stage,
-                                     w.score_stage, true, mm->cap_stream);
-        e = hipStreamEndCapture(mm->cap_stream, &graph);
-        if (rc != 0 || e != hipSuccess || !graph) {
-          if (graph) (void)hipGraphDestroy(graph);
-          hit->failed = true;  // later calls of this shape launch eagerly instead of re-capturing every time
-          return rc != 0 ? rc : (int)e;
-        }
-        e = hipGraphInstantiate(&hit->exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) {
-          hit->exec = nullptr;
-          hit->failed = true;
-          return (int)e;
-        }
-      }
-      e = hipGraphLaunch(hit->exec, hs);
-      if (e != hipSuccess) return (int)e;
-    }
-    e = hipMemcpyAsync(sequences, w.seq_stage, (size_t)B * nret * max_length * sizeof(int64_t), hipMemcpyDeviceToDevice, hs);
-    if (e == hipSuccess && scores) e = hipMemcpyAsync(scores, w.score_stage, (size_t)B * nret * sizeof(float), hipMemcpyDeviceToDevice, hs);
-    if (e != hipSuccess) return (int)e;
-  }
+  TRY(generate_body(m, w, input_ids, mask, B, N, L, K, nret, max_length, trie, comp, sequences, scores, stream));
   if (width_host) {
     int32_t host[2] = {0, 0};
     hipError_t e = hipMemcpyAsync(&host[0], w.width, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);

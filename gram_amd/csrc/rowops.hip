@@ -7,15 +7,15 @@ namespace {
 
 // 16-bit pieces of the 4 values at columns n .. n+3 of a row (gram_split_t): piece p = r16(v - p0 - .. - p_{p-1}); one piece: the
 // plain row [d]; two pieces: the interleaved row [d / 32][2][32] (the layout a GEMM reads its A operand in)
-__device__ __forceinline__ void store_pieces4(bf16* row, int n, f32x4 v, int pieces) {
+__device__ __forceinline__ void store_pieces4(p16* row, int n, f32x4 v, int pieces) {
   for (int pc = 0; pc < pieces; ++pc) {
-    bf16x4 o;
+    p16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      o[e] = (bf16)v[e];
+      o[e] = (p16)v[e];
       v[e] -= (float)o[e];
     }
-    *reinterpret_cast<bf16x4*>(row + (pieces == 2 ? inter_off(n, pc) : n)) = o;
+    *reinterpret_cast<p16x4*>(row + (pieces == 2 ? inter_off(n, pc) : n)) = o;
   }
 }
 
@@ -36,14 +36,14 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ ta
 // xs_out != NULL: the copy is x * xs, xs the power-of-two factor of the row itself (row_xscale), written to xs_out[row]
 template <typename IdT>
 __global__ __launch_bounds__(256) void embed_ex_kernel(const float* __restrict__ table, const IdT* __restrict__ ids,
-                                                       float* __restrict__ x, bf16* __restrict__ xb, float* __restrict__ ss,
+                                                       float* __restrict__ x, p16* __restrict__ xb, float* __restrict__ ss,
                                                        float* __restrict__ xs_out, int nblk, int rows, int d, int pieces) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const f32x4* src = reinterpret_cast<const f32x4*>(table + (size_t)ids[row] * d);
   f32x4* dst = reinterpret_cast<f32x4*>(x + (size_t)row * d);
-  bf16* dstb = xb + (size_t)row * d * pieces;
+  p16* dstb = xb + (size_t)row * d * pieces;
   const bool blocks = nblk == d / 64;  // (d % 64 == 0 then: checked by the launcher)
   f32x4 v[4];  // d <= 1024
   float total = 0.f, minblk = INFINITY;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void embed_ex_kernel(const float* __restrict__
 
 // T5LayerNorm (gram_t5_modeling.py:262-276): fp32 variance, no mean subtraction, no bias.
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                      bf16* __restrict__ out, int rows, int d, float eps, float scale,
+                                                      p16* __restrict__ out, int rows, int d, float eps, float scale,
                                                       const float* __restrict__ pos, int N, int L,
                                                       const int32_t* __restrict__ pmap, int pieces) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   // passage index of this row: row / L, or through the compaction map (flat index b*N + n)
   const int pn = pos ? ((pmap ? pmap[row / L] : row / L) % N) : 0;
   const f32x4* pr = pos ? reinterpret_cast<const f32x4*>(pos + (size_t)pn * d) : nullptr;
-  bf16* o = out + (size_t)row * d * pieces;
+  p16* o = out + (size_t)row * d * pieces;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     int i = lane + it * 64;
@@ -374,10 +374,10 @@ extern "C" int gram_embed_ex_xs(const float* table, const void* ids, int ids_are
   gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, (8.0 + 2.0 * pieces) * rows * d);
   if (ids_are_i64)
     hipLaunchKernelGGL(embed_ex_kernel<int64_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, (const int64_t*)ids,
-                       x, (bf16*)xb, ss, xs_out, nblk, rows, d, pieces);
+                       x, (p16*)xb, ss, xs_out, nblk, rows, d, pieces);
   else
     hipLaunchKernelGGL(embed_ex_kernel<int32_t>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, (const int32_t*)ids,
-                       x, (bf16*)xb, ss, xs_out, nblk, rows, d, pieces);
+                       x, (p16*)xb, ss, xs_out, nblk, rows, d, pieces);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -415,7 +415,7 @@ extern "C" int gram_rmsnorm_bf16_split(const float* x, const float* w, void* out
     L = 1;
   }
   gram_prof::Scope prof(GRAM_K_ROWOPS, (hipStream_t)stream, (4.0 + 2.0 * pieces) * rows * d);
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (bf16*)out, rows, d, eps,
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, (p16*)out, rows, d, eps,
                      scale, pos, N, L, passage_map, pieces);
   GRAM_CHECK_LAUNCH();
   return 0;

@@ -12,7 +12,10 @@
  *   - every pointer is a DEVICE pointer unless the name ends in _host
  *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, nothing allocates,
  *     nothing synchronises (except gram_generate's final 4-byte width read when asked)
- *   - bf16 = 16-bit brain float, row-major; "inner" = n_heads * 64; d_kv must be 64
+ *   - "bf16" in a name or a comment = the library's 16-bit operand type, row-major: IEEE HALF in the default build, bfloat16 only in
+ *     the `make PIECE=bf16` A/B build (gram_piece_format() tells; the names predate the switch).  Every `_bf16` entry point has an
+ *     `_f16` alias (end of this header) that runs only in a library built on IEEE half -- bind those.
+ *   - "inner" = n_heads * 64; d_kv must be 64
  *   - return value: 0 on success, >0 a hipError_t, <0 an argument error (GRAM_E_*)
  */
 #ifndef GRAM_HIP_H
@@ -476,8 +479,11 @@ int gram_prof_reset(void);
  * the recorded events.  dropped = launches not recorded because the pool was full. */
 int gram_prof_collect(int kind, double* total_ms, int64_t* launches, double* work, int64_t* dropped);
 
-/* Time-weighted shader clock (GHz) the chip held inside the persistent ping-pong GEMM launches since the last reset: every workgroup
- * of those kernels adds its s_memtime / s_memrealtime differences around its tile loop to two device counters.  The MFMA peak a
+/* Diagnostic, OFF by default (the product path runs without it): on != 0 makes every workgroup of the persistent ping-pong GEMM stamp
+ * s_memtime / s_memrealtime around its tile loop (two atomics per workgroup and launch) for gram_prof_pp_clock.  Not thread-safe. */
+int gram_prof_pp_clock_enable(int on);
+/* Time-weighted shader clock (GHz) the chip held inside the persistent ping-pong GEMM launches since the last reset (while enabled,
+ * see above): every workgroup of those kernels adds its s_memtime / s_memrealtime differences around its tile loop to two device counters.  The MFMA peak a
  * power-limited chip can be priced against is 2.5 PFLOP/s x this / 2.4 (bench.py's roofline).  Synchronises the device; reset != 0
  * zeroes the counters after reading.  ghz may be NULL. */
 int gram_prof_pp_clock(double* ghz, int reset);
@@ -496,11 +502,6 @@ int gram_debug_stream_read_variant(const void* src, size_t bytes, void* sink, in
 /* A/B hook (bench.py): 0 = decode every row in every step like the reference, 1 = live-row compaction (gram_live_rows_t),
  * -1 = what the GRAM_LIVE_ROWS environment variable says (default 1).  Results are bit-identical either way. */
 int gram_debug_set_live_rows(int on);
-/* A/B hook: 0 = every generate() launches its kernels one by one, 1 = generate() calls with B*K <= 4 096 rows and no
- * compaction are replayed from a HIP graph captured on the second call of a shape, -1 = GRAM_GRAPH decides (default 0:
- * measured without gain on MI355X, see generate.hip). */
-int gram_debug_set_graph(int on);
-
 /* Sensitivity sweeps over the split modes (tests/precision_population.py --sweep): stage s of a generate() computes on the first
  * caps[s] pieces of its operands only (the upper pieces of its activation operands are zeroed before use; the caller zeroes the
  * upper pieces of that stage's weights when it expands them).  caps NULL = no caps.  n must be GRAM_STAGE_COUNT. */
@@ -516,6 +517,25 @@ enum gram_stage {
   GRAM_STAGE_COUNT = 8
 };
 int gram_debug_set_stage_pieces(const int32_t* caps, int n);
+
+/* `_f16` aliases of the entry points whose historical names say `_bf16`: same arguments; they forward in a library built on IEEE half
+ * (gram_piece_format() == 1, the default) and return GRAM_E_ARG in the bfloat16 A/B build, so a binding by name cannot hand the
+ * kernels the wrong 16-bit type. */
+int gram_gemm_f16(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, int epilogue,
+                  const gram_kv_bank_t* bank_host, void* stream);
+int gram_gemm_f16_ex(const void* A, const void* W, void* C, int M, int N, int K, int lda, int ldc, int epilogue,
+                     const gram_kv_bank_t* bank_host, const gram_norm_fusion_t* nf_host, void* stream);
+int gram_gemm_f16_split(const void* A, const void* W, void* C, int M, int N, int kc, int lda, int ldc, int epilogue,
+                        const gram_kv_bank_t* bank_host, const gram_norm_fusion_t* nf_host, const gram_split_t* split_host, void* stream);
+int gram_gemm_f16_lse(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int K, int lda, int ldc, void* stream);
+int gram_gemm_f16_lse_split(const void* A, const void* W, float* logits, float* lse_part, int M, int N, int kc, int lda, int ldc,
+                            const gram_split_t* split_host, void* stream);
+int gram_rmsnorm_f16(const float* x, const float* w, void* out_f16, int rows, int d, float eps, float scale, const float* pos, int N,
+                     int L, void* stream);
+int gram_rmsnorm_f16_map(const float* x, const float* w, void* out_f16, int rows, int d, float eps, float scale, const float* pos,
+                         int N, int L, const int32_t* passage_map, void* stream);
+int gram_rmsnorm_f16_split(const float* x, const float* w, void* out_f16, int rows, int d, float eps, float scale, const float* pos,
+                           int N, int L, const int32_t* passage_map, int pieces, void* stream);
 
 int gram_abi_version(void);
 /* 16-bit operand type this build of the library computes on: 0 = bfloat16, 1 = IEEE half ("f16": make PIECE=f16).  Every "bf16"

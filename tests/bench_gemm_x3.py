@@ -59,6 +59,7 @@ def main():
         for _ in range(2):
             run()
         torch.cuda.synchronize()
+        lib.gram_prof_pp_clock_enable(1)
         _lib.check(lib.gram_prof_pp_clock(None, 1), "clock reset")
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()

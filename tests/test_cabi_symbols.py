@@ -77,3 +77,25 @@ def test_ctypes_structs_match_the_header(tmp_path):
         assert got[(cname, "size")] == ctypes.sizeof(st), cname
         for fname, _ in st._fields_:
             assert got[(cname, fname)] == getattr(st, fname).offset, (cname, fname)
+
+
+def test_f16_aliases_refuse_the_bfloat16_build():
+    """Every `_bf16` entry point has an `_f16` alias (gram_hip.h) so that a binding by name cannot pass the wrong 16-bit type: in the
+    bfloat16 A/B build the aliases return GRAM_E_ARG before anything is launched (no GPU needed to see that)."""
+    import ctypes as C
+    import os
+
+    from gram_amd import _lib
+    _lib.load()  # (torch's HIP runtime first, as for the product library)
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libgram_hip_bf16.so")
+    if not os.path.exists(path):
+        import pytest
+        pytest.skip("libgram_hip_bf16.so not built (make -C gram_amd/csrc PIECE=bf16)")
+    lib = C.CDLL(path)
+    assert lib.gram_piece_format() == 0
+    vp = C.c_void_p
+    lib.gram_gemm_f16.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    assert lib.gram_gemm_f16(None, None, None, 128, 128, 64, 64, 128, 0, None, None) == _lib.E_ARG
+    lib.gram_rmsnorm_f16.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, C.c_int, C.c_int, vp]
+    assert lib.gram_rmsnorm_f16(None, None, None, 4, 128, 1e-6, 1.0, None, 1, 1, None) == _lib.E_ARG
+    assert _lib.load().gram_piece_format() == 1 and all(hasattr(_lib.load(), n) for n in ("gram_gemm_f16_split", "gram_rmsnorm_f16_split"))

@@ -198,6 +198,19 @@ def test_gemm_64_row_tiles_match_128(G, M, N, K):
             assert torch.equal(outs[1][key], outs[v][key]), (v, key)
 
 
+def test_f16_alias_is_the_same_entry_point(G):
+    """gram_gemm_f16 (gram_hip.h: the alias a maintainer should bind) runs gram_gemm_bf16's kernel in the IEEE-half build."""
+    if not G.F16:
+        pytest.skip("bfloat16 build: the _f16 aliases return GRAM_E_ARG (tests/test_cabi_symbols.py)")
+    M, N, K = 300, 256, 192
+    A, W = G.bf(_r(M, K, seed=1)), G.bf(_r(N, K, seed=2, scale=K ** -0.5))
+    c0 = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
+    c1 = torch.zeros_like(c0)
+    _lib.check(G.lib().gram_gemm_bf16(G.p(A), G.p(W), G.p(c0), M, N, K, K, N, _lib.EPI_BF16, None, G.stream()), "bf16 name")
+    _lib.check(G.lib().gram_gemm_f16(G.p(A), G.p(W), G.p(c1), M, N, K, K, N, _lib.EPI_BF16, None, G.stream()), "f16 alias")
+    assert torch.equal(c0, c1) and float(c0.float().abs().max()) > 0
+
+
 def test_gemm_asymmetric_identity(G):
     """A = I with an asymmetric W catches a transposed / row-col swapped fragment mapping."""
     from gram_amd import _lib

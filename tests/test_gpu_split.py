@@ -523,7 +523,8 @@ def test_gemm_stream_matches_tiled(G, pieces, M, N, K):
 
 def test_pp_clock_counters(G):
     """gram_prof_pp_clock: the ping-pong GEMM's workgroups add their s_memtime / s_memrealtime differences to two device counters; the
-    quotient is the shader clock in GHz (bench.py prices the MFMA peak at it).  Zero after a reset, a plausible clock after a launch."""
+    quotient is the shader clock in GHz (bench.py prices the MFMA peak at it).  A diagnostic: nothing is stamped unless it is switched on
+    (gram_prof_pp_clock_enable); zero after a reset, a plausible clock after a launch, the same output bits either way."""
     from gram_amd import _lib
     L_ = G.lib()
     ghz = C.c_double(-1.0)
@@ -532,12 +533,18 @@ def test_pp_clock_counters(G):
     assert ghz.value == 0.0
     M, N, K = 256 * 160, 512, 256
     a32, w32 = _r(M, K, seed=1).to(G.DEV), _r(N, K, seed=2, scale=K ** -0.5).to(G.DEV)
-    y = torch.zeros(M, 2 * N, dtype=G.DT, device=G.DEV)
+    outs = []
     try:
         L_.gram_debug_set_gemm_variant(22)
-        _lib.check(split_gemm(G, G.inter(a32), G.inter(w32), y, M, N, K, _lib.EPI_BF16, True, 0), "pp gemm")
+        for on in (0, 1):
+            L_.gram_prof_pp_clock_enable(on)
+            y = torch.zeros(M, 2 * N, dtype=G.DT, device=G.DEV)
+            _lib.check(split_gemm(G, G.inter(a32), G.inter(w32), y, M, N, K, _lib.EPI_BF16, True, 0), "pp gemm")
+            _lib.check(L_.gram_prof_pp_clock(C.byref(ghz), 1), "clock")
+            outs.append((y, ghz.value))
     finally:
         L_.gram_debug_set_gemm_variant(-1)
-    _lib.check(L_.gram_prof_pp_clock(C.byref(ghz), 1), "clock")
-    print(f"\n[pp clock] {ghz.value:.3f} GHz")
-    assert 0.4 < ghz.value < 2.6, ghz.value
+        L_.gram_prof_pp_clock_enable(0)
+    print(f"\n[pp clock] {outs[1][1]:.3f} GHz")
+    assert outs[0][1] == 0.0 and 0.4 < outs[1][1] < 2.6, outs
+    assert torch.equal(outs[0][0], outs[1][0])
