@@ -46,7 +46,8 @@ namespace {
 // Ablation builds of the ping-pong kernel (`make ABL=n` -> libgram_hip_abl<n>.so, loaded by tests/bench_gemm_x3.py through GRAM_LIB;
 // the product library is built with 0 and contains none of it).  Bits: 1 = no tile-end epilogue (results wrong), 2 = no operand DMA
 // after the prologue, 4 = no LDS fragment reads after the prologue, (8: was the clock stamps, now always on: gram_prof_pp_clock), 16 = the tile-end epilogue without its
-// global stores (fp32: without the stores, the bf16 copy and the partials; the residual loads stay).
+// global stores (fp32: without the stores, the bf16 copy and the partials; the residual loads stay), 32 = the fp32-residual tile-end
+// epilogue without its fp32 store (the 16-bit copy, the partials and the residual load stay).
 #ifndef GRAM_PP_ABL
 #define GRAM_PP_ABL 0
 #endif
@@ -1134,7 +1135,8 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
         if (mr < o.rows && (!(GRAM_PP_ABL & 16) || o.rows < -12345)) {
           f32x4* pc = reinterpret_cast<f32x4*>(o.c + ((uint32_t)mr * o.ldc_b + c * 16));
           if constexpr (EPI == GRAM_EPI_F32_ADD) val += res[p * 4 + it];
-          *pc = val;
+          if (!(GRAM_PP_ABL & 32) || o.rows < -12345) *pc = val;  // (ablation bit 32: the epilogue without its fp32 store -- the
+          //                                            bytes a residual stream kept as its two pieces only would move: DESIGN.md 9.1)
           if constexpr (EPI == GRAM_EPI_F32_ADD) {
             if (o.xb) {
               const f32x4 xv = val * __shfl(xsl, p * 16 + it * 4 + (lane >> 4), 64);  // the 16-bit copy carries the row's power-of-two factor

@@ -27,7 +27,7 @@ def main():
     d, F, V = 768, 3072, 32128
     shapes = [("enc qkv", Me, 3 * d, d, _lib.EPI_BF16), ("enc o", Me, d, d, _lib.EPI_F32_ADD), ("enc wi", Me, F, d, _lib.EPI_BF16_RELU),
               ("enc wo", Me, d, F, _lib.EPI_F32_ADD), ("dec qkv", Md, 3 * d, d, _lib.EPI_BF16), ("dec wi", Md, F, d, _lib.EPI_BF16_RELU),
-              ("dec wo", Md, d, F, _lib.EPI_F32_ADD), ("lm_head", Md, V, d, "lse")]
+              ("dec wo", Md, d, F, _lib.EPI_F32_ADD), ("lm_head", Md, V, d, "lse"), ("kv bank", Me, 12 * 2 * d, d, "kv")]
     g = torch.Generator(device=G.DEV).manual_seed(0)
     for name, M, N, K, epi in shapes:
         if a.only and a.only != name:
@@ -40,6 +40,14 @@ def main():
             part = torch.empty(M, N // 64 + 1, 2, dtype=torch.float32, device=G.DEV)
             sp = _lib.Split(2, 0, 0, 0, 0.0)
             run = lambda: _lib.check(lib.gram_gemm_bf16_lse_split(G.p(A), G.p(W), None, G.p(part), M, N, K, 2 * K, 0, C.byref(sp), G.stream()), "lse")
+        elif epi == "kv":
+            Bu, S, H, layers = a.batch, 384, 12, 12
+            k = torch.empty(2, layers, Bu, H, S, 64, dtype=G.DT, device=G.DEV)
+            vt = torch.empty(2, layers, Bu, H, S // 32, 64, 32, dtype=G.DT, device=G.DEV)
+            bank = _lib.KVBank(k.data_ptr(), vt.data_ptr(), layers, Bu, H, S)
+            sp = _lib.Split(2, 0, 0, k[0].numel(), 0.0)
+            keep = [k, vt]
+            run = lambda: _lib.check(lib.gram_gemm_bf16_split(G.p(A), G.p(W), None, M, N, K, 2 * K, 0, _lib.EPI_KV_BANK, C.byref(bank), None, C.byref(sp), G.stream()), "kv")
         elif epi == _lib.EPI_F32_ADD:
             x = torch.zeros(M, N, dtype=torch.float32, device=G.DEV)
             xb = torch.empty(M, 2 * N, dtype=G.DT, device=G.DEV)
