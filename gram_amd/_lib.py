@@ -135,8 +135,6 @@ SIGNATURES = {
     "gram_debug_set_gemm_variant": (C.c_int, [C.c_int]),
     "gram_gemm_stream_max_m": (C.c_int, []),
     "gram_debug_set_live_rows": (C.c_int, [C.c_int]),
-    "gram_debug_set_xa_pw_min": (C.c_int, [C.c_long]),
-    "gram_debug_set_xa_records": (C.c_int, [C.c_int]),
     "gram_debug_set_stage_pieces": (C.c_int, [C.POINTER(i32), C.c_int]),
     "gram_debug_stream_read": (C.c_int, [vp, C.c_size_t, vp, vp]),
     "gram_debug_stream_read_variant": (C.c_int, [vp, C.c_size_t, vp, C.c_int, C.c_int, vp]),

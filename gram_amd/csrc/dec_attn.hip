@@ -54,12 +54,10 @@ __device__ __forceinline__ int ksw(int row) { return ((row >> 1) & 1) | (((row >
 __device__ __forceinline__ int vsw(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
 constexpr int XA_TILE = 4096;  // one K tile or one V^T tile of a 32-key step, per piece
-int g_xa_records = 0;          // gram_debug_set_xa_records (read-side layout experiment of cross_attn_kernel; never set by the product path)
-long g_xa_pw_min = -1;         // gram_debug_set_xa_pw_min: (user, head) items from which cross_attn_pw_kernel is used; -1 = GRAM_XA_PW_MIN / 8192
 
 // The two places of the cross-attention whose rounding depends on an fma-contraction decision, spelled out once for both kernels below
-// (cross_attn_kernel with two waves per (user, head) and cross_attn_pw_kernel with one wave and two accumulator sets must return the
-// same bits: a user's result does not depend on the batch size that picks the kernel, and hipcc decides contraction per call site).
+// (every instantiation of the kernel must return the same bits for the same (user, head) -- a user's result does not depend on the batch
+// it is scored in -- and hipcc decides contraction per call site).
 __device__ __forceinline__ float xa_l_update(float l, float alpha, float ps) { return __builtin_fmaf(l, alpha, ps); }
 // merge of the two partial softmaxes (m, l, O) of a (user, head): weights and 1 / l
 __device__ __forceinline__ void xa_merge_w(float m0, float m1, float l0, float l1, float& w0, float& w1, float& inv) {
@@ -81,7 +79,7 @@ template <int NT, bool LIVE, int S, int NW, int R>
 __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     const p16* __restrict__ q, const p16* __restrict__ kbank, const p16* __restrict__ vtbank,
     const uint8_t* __restrict__ mask, p16* __restrict__ out, int K, int H, int Sk, const int32_t* __restrict__ users,
-    const int32_t* __restrict__ rowpos, long q_pstride, long bank_pstride, const uint32_t* __restrict__ key_bits, int rec) {
+    const int32_t* __restrict__ rowpos, long q_pstride, long bank_pstride, const uint32_t* __restrict__ key_bits) {
   using T = SplitTab<S>;
   constexpr int NB = NT * 16;                     // padded beams
   // R == 0: "half slot" -- ONE region per wave that holds a step's K tiles, then (once their fragments are in registers) its V^T tiles,
@@ -105,9 +103,6 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
   const int inner = H * 64;
   const char* kb = reinterpret_cast<const char*>(kbank + ((size_t)b * H + h) * Sk * 64);
   const char* vt = reinterpret_cast<const char*>(vtbank + ((size_t)b * H + h) * 64 * Sk);
-  // rec != 0 (gram_debug_set_xa_records: a READ-SIDE experiment, results are garbage unless the bank were written that way): the
-  // bank as step-major records -- per (user, head) and 32-key step one contiguous [K tiles of every piece | V^T tiles of every piece]
-  const char* kr = reinterpret_cast<const char*>(kbank) + ((size_t)b * H + h) * (size_t)(Sk >> 5) * (2 * S * XA_TILE);
   const uint8_t* mk = mask + (size_t)b * Sk;
 
   p16x8 qf[S][NT][2];  // query fragments: loaded once the ring is primed (below)
@@ -201,8 +196,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     const uint32_t dst = ring0 + slot * STAGE;
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) {
-      const char* kbase = rec ? kr + (size_t)step * (2 * S * XA_TILE) + pc * XA_TILE
-                              : kb + (size_t)pc * bank_pstride * 2 + (size_t)step * (32 * 128);
+      const char* kbase = kb + (size_t)pc * bank_pstride * 2 + (size_t)step * (32 * 128);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if constexpr ((GRAM_XA_NT & 1) != 0) dma16_nt(dst + pc * PSTR + i * 1024, koff[i], kbase);
@@ -214,8 +208,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     const uint32_t dst = ring0 + slot * STAGE;
 #pragma unroll
     for (int pc = 0; pc < S; ++pc) {
-      const char* vbase = rec ? kr + (size_t)step * (2 * S * XA_TILE) + (S + pc) * XA_TILE
-                              : vt + (size_t)pc * bank_pstride * 2 + (size_t)step * 4096;
+      const char* vbase = vt + (size_t)pc * bank_pstride * 2 + (size_t)step * 4096;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if constexpr ((GRAM_XA_NT & 2) != 0) dma16_nt(dst + pc * PSTR + VOFF + i * 1024, voff[i], vbase);
@@ -500,7 +493,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
   __syncthreads();
   for (int idx = tid; idx < K * 16; idx += NW * 64) {
     const int beam = idx >> 4, d4 = (idx & 15) * 4;
-    if constexpr (NW == 2) {  // (the arithmetic cross_attn_pw_kernel does in registers: same bits)
+    if constexpr (NW == 2) {
       float w0, w1, inv2;
       xa_merge_w(sm_m[beam], sm_m[NB + beam], sm_l[beam], sm_l[NB + beam], w0, w1, inv2);
       f32x4 v = xa_merge_o(*reinterpret_cast<const f32x4*>(sm_o + ((size_t)beam) * 64 + d4),
@@ -554,362 +547,6 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// cross_attn_pw_kernel ("persistent wave"): the same arithmetic for large grids.  cross_attn_kernel gives every (user, head) its own
-// workgroup of two waves; at S = 384 keys an item is 12 steps of 16 KB -- 6 per wave -- and every item pays a prologue (key bits, query
-// fragments, an empty DMA queue) and a tail (LDS merge, stores) with nothing in flight: the same kernel reads 6.3 TB/s at S = 2 688 and
-// 5.7 at S = 384.  Here ONE wave walks a strided list of (user, head) items and its DMA queue never drains: the first K / V^T tiles of
-// the next item are requested before the current item's results are merged and stored, its query fragments are loaded as soon as the
-// current item's last S^T is done, its key bits one item ahead.  The two waves of cross_attn_kernel become two ACCUMULATOR SETS -- the
-// valid steps are dealt to them round-robin exactly as they were dealt to the waves, each set runs the same online softmax, and the
-// sets are merged with the same arithmetic (xa_merge_*) -- so the results are bit-identical to cross_attn_kernel<.., NW = 2, R = 1>,
-// which small grids keep (two waves per item halve a one-user step's latency).  One 16-KB stage per wave, consumed and re-filled in
-// halves as there; no barrier, no LDS merge.
-template <int NT, bool LIVE, int S>
-__global__ __launch_bounds__(64) void cross_attn_pw_kernel(
-    const p16* __restrict__ q, const p16* __restrict__ kbank, const p16* __restrict__ vtbank, p16* __restrict__ out, int K, int H,
-    int Sk, const int32_t* __restrict__ users, const int32_t* __restrict__ rowpos, long q_pstride, long bank_pstride,
-    const uint32_t* __restrict__ key_bits, int n_items) {
-  using T = SplitTab<S>;
-  constexpr int PSTR = 2 * XA_TILE, VOFF = XA_TILE;  // one stage: per piece [K tile | V^T tile]
-  constexpr int NQ = 2 * S * NT;  // query-fragment loads of an item
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-  const int inner = H * 64, nsteps = Sk >> 5, G = gridDim.x;
-
-  uint32_t koff[4], voff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int kr = 8 * i + (lane >> 3);
-    koff[i] = (uint32_t)(kr * 128 + (((lane & 7) ^ ksw(kr)) << 4));
-    const int d = 16 * i + (lane >> 2);
-    voff[i] = (uint32_t)(d * 64 + (((lane & 3) ^ vsw(d)) << 4));
-  }
-  const uint32_t ring0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int krow = 8 * (c >> 2) + (c & 3);
-
-  // item -> (user, head); all wave-uniform
-  auto locate = [&](int item, int& b, int& h) {
-    const int y = item / H;
-    h = item - y * H;
-    b = LIVE ? users[y] : y;
-  };
-  auto issue_k = [&](int b, int h, int step) {
-    const char* kb = reinterpret_cast<const char*>(kbank + ((size_t)b * H + h) * Sk * 64);
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      const char* kbase = kb + (size_t)pc * bank_pstride * 2 + (size_t)step * (32 * 128);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr ((GRAM_XA_NT & 1) != 0) dma16_nt(ring0 + pc * PSTR + i * 1024, koff[i], kbase);
-        else dma16(ring0 + pc * PSTR + i * 1024, koff[i], kbase);
-      }
-    }
-  };
-  auto issue_v = [&](int b, int h, int step) {
-    const char* vt = reinterpret_cast<const char*>(vtbank + ((size_t)b * H + h) * 64 * Sk);
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc) {
-      const char* vbase = vt + (size_t)pc * bank_pstride * 2 + (size_t)step * 4096;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr ((GRAM_XA_NT & 2) != 0) dma16_nt(ring0 + pc * PSTR + VOFF + i * 1024, voff[i], vbase);
-        else dma16(ring0 + pc * PSTR + VOFF + i * 1024, voff[i], vbase);
-      }
-    }
-  };
-  p16x8 kf[S][2][2], vf[S][4], pf[S][NT], qf[S][NT][2];
-  auto read_k = [&]() {
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int kd = 0; kd < 2; ++kd) {
-          const int r = krow + 4 * t;
-          kf[pc][t][kd] = *reinterpret_cast<const p16x8*>(smem + pc * PSTR + r * 128 + (((g + 4 * kd) ^ ksw(r)) << 4));
-        }
-  };
-  auto read_v = [&]() {
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const int d = 16 * mt + c;
-        vf[pc][mt] = *reinterpret_cast<const p16x8*>(smem + pc * PSTR + VOFF + d * 64 + ((g ^ vsw(d)) << 4));
-      }
-  };
-  // EXACTLY NQ load instructions per call, whatever the beams (rows that do not exist load row 0 and are zeroed afterwards): the
-  // counted wait at an item boundary relies on the number of vector-memory instructions issued behind a step's V^T tiles
-  auto load_q = [&](int b, int h) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int beam = 16 * nt + c;
-      int qrow = beam < K ? b * K + beam : -1;
-      if constexpr (LIVE) {
-        if (qrow >= 0) qrow = rowpos[qrow];
-      }
-      const size_t qr = qrow >= 0 ? (size_t)qrow : 0;
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc)
-#pragma unroll
-        for (int kd = 0; kd < 2; ++kd) {
-          const p16x8 v = ld_global_b128(q + pc * q_pstride + qr * inner + h * 64 + 32 * kd + 8 * g);
-          qf[pc][nt][kd] = qrow >= 0 ? v : zero_bf16x8();
-        }
-    }
-  };
-  // ... and exactly two here (steps past the end read word 0 and are zeroed)
-  auto load_bits = [&](int b, uint32_t& w0, uint32_t& w1) {
-    const uint32_t a0 = key_bits[(size_t)b * 128 + (lane < nsteps ? lane : 0)];
-    const uint32_t a1 = key_bits[(size_t)b * 128 + (lane + 64 < nsteps ? lane + 64 : 0)];
-    w0 = lane < nsteps ? a0 : 0u;
-    w1 = lane + 64 < nsteps ? a1 : 0u;
-  };
-  // valid-step masks of an item from its key-bit words (a user without any valid key keeps every step, as in cross_attn_kernel)
-  auto valid_steps = [&](uint32_t w0, uint32_t w1, unsigned long long& v0, unsigned long long& v1) {
-    v0 = __ballot(w0 != 0u);
-    v1 = __ballot(w1 != 0u);
-    if ((v0 | v1) == 0ull) {
-      v0 = nsteps >= 64 ? ~0ull : ((1ull << nsteps) - 1ull);
-      v1 = nsteps > 64 ? ((nsteps >= 128 ? ~0ull : ((1ull << (nsteps - 64)) - 1ull))) : 0ull;
-    }
-    v0 = __builtin_amdgcn_readfirstlane((unsigned)v0) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v0 >> 32)) << 32);
-    v1 = __builtin_amdgcn_readfirstlane((unsigned)v1) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v1 >> 32)) << 32);
-  };
-  auto next_valid = [&](int s, unsigned long long v0, unsigned long long v1) -> int {
-    for (s = s + 1; s < nsteps; ++s)
-      if (((s < 64 ? (v0 >> s) : (v1 >> (s - 64))) & 1ull) != 0ull) return s;
-    return nsteps;
-  };
-
-  f32x4 o[2][4][NT];
-  float m[2][NT], l[2][NT];
-  auto reset = [&]() {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        m[a][nt] = GRAM_FMIN;
-        l[a][nt] = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) o[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-  };
-  uint32_t kb0, kb1, kn0 = 0u, kn1 = 0u;  // key bits of the current item / of the next one
-  // S^T, masked online softmax and the rescaling of accumulator set `a` (the step arithmetic of cross_attn_kernel, on set a)
-  auto math_qk = [&](int step, auto a_c) {
-    constexpr int a = decltype(a_c)::value;
-    const uint32_t kword = step < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)kb0, step) : (uint32_t)__builtin_amdgcn_readlane((int)kb1, step - 64);
-    const uint32_t kbits = kword >> (8 * g);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x4 s[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pr = 0; pr < T::NP; ++pr) {
-          acc = mfma16(kf[T::A[pr]][t][0], qf[T::B[pr]][nt][0], acc);
-          acc = mfma16(kf[T::A[pr]][t][1], qf[T::B[pr]][nt][1], acc);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = ((kbits >> (4 * t + j)) & 1u) ? acc[j] : GRAM_FMIN;
-        s[t] = acc;
-      }
-      float tm = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
-                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-      tm = fmaxf(tm, __shfl_xor(tm, 16, 64));
-      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-      const float mn = fmaxf(m[a][nt], tm);
-      const float alpha = __expf(m[a][nt] - mn);
-      m[a][nt] = mn;
-      float ps = 0.f;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float e = __expf(s[t][j] - mn);
-          ps += e;
-#pragma unroll
-          for (int pc = 0; pc < S; ++pc) {
-            const p16 eb = (p16)e;
-            pf[pc][nt][4 * t + j] = eb;
-            e -= (float)eb;
-          }
-        }
-      l[a][nt] = xa_l_update(l[a][nt], alpha, ps);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) o[a][mt][nt] *= alpha;
-    }
-  };
-  auto math_pv = [&](auto a_c) {
-    constexpr int a = decltype(a_c)::value;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int pr = 0; pr < T::NP; ++pr) o[a][mt][nt] = mfma16(vf[T::A[pr]][mt], pf[T::B[pr]][nt], o[a][mt][nt]);
-  };
-  // merge the two sets and store the item's rows (lane: beam 16 nt + c, dims 16 mt + 4 g ..+3)
-  auto finish = [&](int b, int h) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      float l0 = l[0][nt], l1 = l[1][nt];
-      l0 += __shfl_xor(l0, 16, 64);
-      l0 += __shfl_xor(l0, 32, 64);
-      l1 += __shfl_xor(l1, 16, 64);
-      l1 += __shfl_xor(l1, 32, 64);
-      float w0, w1, inv;
-      xa_merge_w(m[0][nt], m[1][nt], l0, l1, w0, w1, inv);
-      const int beam = 16 * nt + c;
-      int orow = beam < K ? b * K + beam : -1;
-      if constexpr (LIVE) {
-        if (orow >= 0) orow = rowpos[orow];
-      }
-      if (orow >= 0) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          f32x4 v = xa_merge_o(o[0][mt][nt], o[1][mt][nt], w0, w1, inv);
-#pragma unroll
-          for (int pc = 0; pc < S; ++pc) {
-            p16x4 r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              r[e] = (p16)v[e];
-              v[e] -= (float)r[e];
-            }
-            const int n = h * 64 + 16 * mt + 4 * g;
-            *reinterpret_cast<p16x4*>(out + (size_t)orow * inner * S + (S == 2 ? inter_off(n, pc) : n)) = r;
-          }
-        }
-      }
-    }
-  };
-
-  int item = blockIdx.x;
-  if (item >= n_items) return;
-  int b, h;
-  locate(item, b, h);
-  load_bits(b, kb0, kb1);
-  if (item + G < n_items) {
-    int nb, nh;
-    locate(item + G, nb, nh);
-    load_bits(nb, kn0, kn1);
-  }
-  load_q(b, h);
-  wait_vm<0>();
-  unsigned long long v0, v1;
-  valid_steps(kb0, kb1, v0, v1);
-  reset();
-  int cur = next_valid(-1, v0, v1);
-  issue_k(b, h, cur);
-  issue_v(b, h, cur);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int pc = 0; pc < S; ++pc)
-#pragma unroll
-      for (int kd = 0; kd < 2; ++kd) asm volatile("" : "+v"(qf[pc][nt][kd]));
-  int odd = 0;  // parity of the current step's ordinal among the item's valid steps: the accumulator set
-  while (true) {
-    const int nxt = next_valid(cur, v0, v1);
-    const bool last = nxt >= nsteps;
-    const int nitem = item + G;
-    const bool more = last && nitem < n_items;
-    int nb = 0, nh = 0, nfirst = 0;
-    unsigned long long nv0 = 0ull, nv1 = 0ull;
-    if (more) {
-      locate(nitem, nb, nh);
-      valid_steps(kn0, kn1, nv0, nv1);
-      nfirst = next_valid(-1, nv0, nv1);
-    }
-    wait_vm<4 * S>();  // all but the newest half-stage (this step's V^T tiles): its K tiles have landed
-    read_k();
-    if (!last || more) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the K fragments are in registers before their tiles are re-filled
-      if (!last) issue_k(b, h, nxt);
-      else issue_k(nb, nh, nfirst);
-    }
-    if (odd) math_qk(cur, std::integral_constant<int, 1>{});
-    else math_qk(cur, std::integral_constant<int, 0>{});
-    if (more) {
-      // the next item's query fragments (this item's are dead) and the key bits of the item after it; they fly with the tiles
-      load_q(nb, nh);
-      kb0 = kn0;  // (the rest of this item needs no key bits: its last S^T is done)
-      kb1 = kn1;
-      {
-        int xb = nb, xh = nh;  // (no item after the next: the loads still go out -- the count below is exact -- and are ignored)
-        if (nitem + G < n_items) locate(nitem + G, xb, xh);
-        load_bits(xb, kn0, kn1);
-      }
-      wait_vm<4 * S + NQ + 2>();  // issued behind this step's V^T tiles: the next K tiles, NQ query loads, two key-bit loads
-    } else if (!last) {
-      wait_vm<4 * S>();  // (newest: the next step's K tiles)
-    } else {
-      wait_vm<0>();
-    }
-    read_v();
-    if (!last || more) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!last) issue_v(b, h, nxt);
-      else issue_v(nb, nh, nfirst);
-    }
-    if (odd) math_pv(std::integral_constant<int, 1>{});
-    else math_pv(std::integral_constant<int, 0>{});
-    if (!last) {
-      cur = nxt;
-      odd ^= 1;
-      continue;
-    }
-    finish(b, h);
-    if (!more) break;
-    wait_vm<0>();  // this item's stores, the next item's queries / key bits -- and its first tiles, which have had the merge to land
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int pc = 0; pc < S; ++pc)
-#pragma unroll
-        for (int kd = 0; kd < 2; ++kd) asm volatile("" : "+v"(qf[pc][nt][kd]));
-    asm volatile("" : "+v"(kn0), "+v"(kn1));
-    item = nitem;
-    b = nb;
-    h = nh;
-    v0 = nv0;
-    v1 = nv1;
-    cur = nfirst;
-    odd = 0;
-    reset();
-  }
-}
-
-template <int NT, int S>
-int launch_cross_pw(const void* q, const void* k, const void* vt, void* out, int B, int K, int H, int Sk, const int32_t* users,
-                    const int32_t* rowpos, long q_ps, long bank_ps, const uint32_t* key_bits, hipStream_t st) {
-  constexpr int smem = S * 2 * XA_TILE;
-  static int waves = 0;  // resident waves of this kernel on the device
-  if (waves == 0) {
-    int per_cu = 0, cus = 0, dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e == hipSuccess)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(cross_attn_pw_kernel<NT, false, S>), 64, smem);
-    if (e != hipSuccess) return (int)e;
-    waves = (per_cu > 0 ? per_cu : 8) * (cus > 0 ? cus : 256);
-  }
-  const int n_items = B * H;
-  const int grid = n_items < waves ? n_items : waves;
-  if (users)
-    hipLaunchKernelGGL((cross_attn_pw_kernel<NT, true, S>), dim3(grid), dim3(64), smem, st, (const p16*)q, (const p16*)k, (const p16*)vt,
-                       (p16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits, n_items);
-  else
-    hipLaunchKernelGGL((cross_attn_pw_kernel<NT, false, S>), dim3(grid), dim3(64), smem, st, (const p16*)q, (const p16*)k, (const p16*)vt,
-                       (p16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits, n_items);
-  GRAM_CHECK_LAUNCH();
-  return 0;
-}
-
 template <int NT, int S, int NW, int R>
 int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* mask, void* out, int B, int K, int H, int Sk,
                  const int32_t* users, const int32_t* rowpos, long q_ps, long bank_ps, const uint32_t* key_bits, hipStream_t st) {
@@ -929,10 +566,10 @@ int launch_cross(const void* q, const void* k, const void* vt, const uint8_t* ma
   }
   if (users)
     hipLaunchKernelGGL((cross_attn_kernel<NT, true, S, NW, R>), dim3(H, B), dim3(NW * 64), smem, st, (const p16*)q, (const p16*)k,
-                       (const p16*)vt, mask, (p16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits, g_xa_records);
+                       (const p16*)vt, mask, (p16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits);
   else
     hipLaunchKernelGGL((cross_attn_kernel<NT, false, S, NW, R>), dim3(H, B), dim3(NW * 64), smem, st, (const p16*)q, (const p16*)k,
-                       (const p16*)vt, mask, (p16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits, g_xa_records);
+                       (const p16*)vt, mask, (p16*)out, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits);
   GRAM_CHECK_LAUNCH();
   return 0;
 }
@@ -999,16 +636,15 @@ int launch_cross_v(const void* q, const void* k, const void* vt, const uint8_t* 
   // CU: (2, 0) 5.80, (1, 0) 5.80, (4, 0) 5.77 TB/s against 5.75-5.94 for (2, 1) in the same run: no gain, profiles/r03_cross_attn_half_slot_ab.txt)
   // (with the stage consumed and re-filled in halves, ONE stage wins there too: K = 50, S = 2 688, H = 16, same box: (1, 1) 4.65 / 5.75 TB/s
   // against (1, 2) 3.97 / 5.12, (4, 1) 4.19 / 5.37, (2, 2) 3.72 / 5.02 -- profiles/r02m_cross_attn_k50_variants.txt)
-  if constexpr (NT >= 3) {
-    return launch_cross<NT, S, 1, 1>(XA_ARGS);
-  } else {
-    // large grids: one persistent wave per list of (user, head) items, bit-identical to the two-wave kernel (cross_attn_pw_kernel);
-    // GRAM_XA_PW_MIN = items from which it is used (A/B hook; 0 = never)
-    static const long pw_env = getenv("GRAM_XA_PW_MIN") ? atol(getenv("GRAM_XA_PW_MIN")) : 8192;
-    const long pw_min = g_xa_pw_min >= 0 ? g_xa_pw_min : pw_env;
-    if (key_bits && pw_min > 0 && (long)B * H >= pw_min) return launch_cross_pw<NT, S>(q, k, vt, out, B, K, H, Sk, users, rowpos, q_ps, bank_ps, key_bits, st);
-    return launch_cross<NT, S, 2, 1>(XA_ARGS);
-  }
+  // (round 4, both open ideas of round 3 built and measured, neither kept -- commit e681937, profiles/r04e_*, r04f_*: a PERSISTENT-WAVE
+  // kernel -- one wave per strided list of (user, head) items, the next item's first tiles requested before the current one is merged and
+  // stored, the two waves as two accumulator sets, bit-identical to this kernel on 8 shapes incl. live rows -- ran the bench's
+  // cross-attention in 164.4 ms per step against 160.8 (its 205 VGPRs leave 8 waves per CU where five two-wave workgroups fill the LDS);
+  // and the bank addressed as STEP-MAJOR 16-KB RECORDS (read side only) read 5.78 TB/s against 5.86 for the planar bank, with +-5 %
+  // between processes for either: the per-item prologue / tail and the four planar streams are not what holds the kernel at ~0.87 of the
+  // box's streaming read)
+  if constexpr (NT >= 3) return launch_cross<NT, S, 1, 1>(XA_ARGS);
+  else return launch_cross<NT, S, 2, 1>(XA_ARGS);
 #undef XA_ARGS
 }
 
@@ -1138,16 +774,6 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const p16* __restric
 }
 
 }  // namespace
-
-extern "C" int gram_debug_set_xa_records(int on) {
-  g_xa_records = on != 0;
-  return 0;
-}
-
-extern "C" int gram_debug_set_xa_pw_min(long items) {
-  g_xa_pw_min = items;
-  return 0;
-}
 
 extern "C" int gram_mask_key_bits(const uint8_t* mask, uint32_t* key_bits, int B, int S, void* stream) {
   if (!mask || !key_bits || B < 1 || S < 32 || (S & 31) || S > 4096 || (reinterpret_cast<uintptr_t>(mask) & 15)) return GRAM_E_ARG;

@@ -502,15 +502,6 @@ int gram_debug_stream_read_variant(const void* src, size_t bytes, void* sink, in
 /* A/B hook (bench.py): 0 = decode every row in every step like the reference, 1 = live-row compaction (gram_live_rows_t),
  * -1 = what the GRAM_LIVE_ROWS environment variable says (default 1).  Results are bit-identical either way. */
 int gram_debug_set_live_rows(int on);
-/* A/B hook: number of (user, head) items from which the cross-attention runs on its persistent-wave kernel (one wave per strided list
- * of items, the DMA queue kept full across items) instead of one two-wave workgroup per item; 0 = never, -1 = GRAM_XA_PW_MIN or the
- * default 8 192.  Results are bit-identical either way.  Needs key_bits (gram_mask_key_bits) and K <= 32. */
-int gram_debug_set_xa_pw_min(long items);
-/* Measurement hook (tests/bench_xattn.py, never the product path): != 0 makes the per-item cross-attention kernel ADDRESS its bank as
- * step-major records -- per (user, head) and 32-key step one contiguous [K tile of every piece | V^T tile of every piece] starting at
- * k_layer -- to time that read pattern against the planar bank's; the results are meaningless (nothing writes such a bank). */
-int gram_debug_set_xa_records(int on);
-
 /* Sensitivity sweeps over the split modes (tests/precision_population.py --sweep): stage s of a generate() computes on the first
  * caps[s] pieces of its operands only (the upper pieces of its activation operands are zeroed before use; the caller zeroes the
  * upper pieces of that stage's weights when it expands them).  caps NULL = no caps.  n must be GRAM_STAGE_COUNT. */

@@ -33,18 +33,8 @@ def one(pieces, B=4096, H=12, S=384, K=20, reps=20, use_bits=True, layers=1):
     bits = torch.zeros(B, 128, dtype=torch.int32, device=dev)
     _lib.check(lib.gram_mask_key_bits(mask.data_ptr(), bits.data_ptr(), B, S, st), "bits")
 
-    rec = int(os.environ.get("XA_RECORDS", "0"))  # read-side experiment: the bank addressed as step-major 16-KB records
-    if rec:
-        lib.gram_debug_set_xa_records(1)
-        lib.gram_debug_set_xa_pw_min(0)
-        assert layers % 2 == 0, "records mode: a record layer is two planar K layers' worth of bytes"
-    if os.environ.get("XA_PW_MIN") is not None:
-        lib.gram_debug_set_xa_pw_min(int(os.environ["XA_PW_MIN"]))
-
     def run():
         ly = it[0] % layers
-        if rec:
-            ly = 2 * (it[0] % (layers // 2))
         it[0] += 1
         _lib.check(lib.gram_cross_attn_decode_split(q.data_ptr(), kbs.data_ptr() + ly * lstride, vts.data_ptr() + ly * lstride, mask.data_ptr(), out.data_ptr(), B, K, H, S,
                                                     None, None, pieces, q[0].numel(), pstride, bits.data_ptr() if use_bits else None, st), "xattn")

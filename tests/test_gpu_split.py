@@ -239,66 +239,6 @@ def test_split_cross_attn(G, K, S):
     assert e < 10 * tol(G)
 
 
-@pytest.mark.parametrize("pieces", [2, 1])
-@pytest.mark.parametrize("K,S,B,H", [(20, 384, 40, 12), (5, 96, 70, 4), (32, 160, 33, 2), (16, 2688, 6, 12)])
-def test_cross_attn_persistent_wave_kernel_is_bit_identical(G, K, S, B, H, pieces):
-    """cross_attn_pw_kernel (one wave walks a strided list of (user, head) items, its DMA queue never drains, the two waves of the
-    per-item kernel as two accumulator sets) against cross_attn_kernel on the same inputs: identical bits -- ragged masks with fully
-    masked 32-key steps, a user without any valid key, users with one valid step, more items than resident waves and fewer, and the
-    live-row form (a subset of users, compact rows, dead beams)."""
-    from gram_amd import _lib
-    inner = H * 64
-    g = torch.Generator().manual_seed(K * 1000 + S + pieces)
-    q32 = (torch.randn(B * K, inner, generator=g) * 0.3).to(G.DEV)
-    k32 = torch.randn(B, H, S, 64, generator=g).to(G.DEV)
-    v32 = torch.randn(B, H, S, 64, generator=g).to(G.DEV)
-    if pieces == 2:
-        q, kb, vt = G.pieces_of(q32), G.pieces_of(k32), G.pieces_of(G.vt_blocked(v32.transpose(2, 3).contiguous()))
-        qps, bps = q[0].numel(), kb[0].numel()
-    else:
-        q, kb, vt = G.bf(q32), G.bf(k32), G.bf(G.vt_blocked(v32.transpose(2, 3).contiguous()))
-        qps, bps = 0, 0
-    mask = torch.rand(B, S, generator=g) > 0.3
-    mask[1, : S // 2] = False
-    mask[2] = False                      # no valid key at all: every step is kept (uniform softmax, like the reference)
-    mask[3] = False
-    mask[3, S - 7] = True                # a single valid step
-    for b in range(4, B, 3):             # realistic raggedness: whole passages padded away
-        mask[b, (1 + b % max(S // 32, 1)) * 32 // 2 * 2:] = False
-    m8 = mask.to(G.DEV).view(torch.uint8).contiguous()
-    bits = torch.full((B, 128), -1, dtype=torch.int32, device=G.DEV)
-    _lib.check(G.lib().gram_mask_key_bits(G.p(m8), G.p(bits), B, S, G.stream()), "bits")
-    # live-row form: every other user, some beams dead
-    users = torch.arange(0, B, 2, dtype=torch.int32, device=G.DEV)
-    rowpos = torch.full((B * K,), -1, dtype=torch.int32, device=G.DEV)
-    live = [(int(u), k) for u in users.tolist() for k in range(K) if (u + k) % 3 != 0]
-    for i, (u, k) in enumerate(live):
-        rowpos[u * K + k] = i
-    ql = q32[[u * K + k for u, k in live]]
-    qlive = G.pieces_of(ql) if pieces == 2 else G.bf(ql)
-    qlps = qlive[0].numel() if pieces == 2 else 0
-    got = {}
-    try:
-        for name, pw_min in (("per_item", 0), ("persistent", 1)):
-            G.lib().gram_debug_set_xa_pw_min(pw_min)
-            out = torch.zeros(B * K, pieces * inner, dtype=G.DT, device=G.DEV)
-            _lib.check(G.lib().gram_cross_attn_decode_split(G.p(q), G.p(kb), G.p(vt), G.p(m8), G.p(out), B, K, H, S, None, None, pieces,
-                                                            qps, bps, G.p(bits), G.stream()), name)
-            outl = torch.zeros(len(live), pieces * inner, dtype=G.DT, device=G.DEV)
-            _lib.check(G.lib().gram_cross_attn_decode_split(G.p(qlive), G.p(kb), G.p(vt), G.p(m8), G.p(outl), users.numel(), K, H, S,
-                                                            G.p(users), G.p(rowpos), pieces, qlps, bps, G.p(bits), G.stream()), name + " live")
-            torch.cuda.synchronize()
-            got[name] = (out, outl)
-    finally:
-        G.lib().gram_debug_set_xa_pw_min(-1)
-    assert torch.equal(got["per_item"][0], got["persistent"][0])
-    assert torch.equal(got["per_item"][1], got["persistent"][1])
-    assert bool(torch.isfinite(got["persistent"][0].float()).all()) and float(got["persistent"][0].float().abs().max()) > 0
-    # and the live rows are the full call's rows
-    full = got["persistent"][0][[u * K + k for u, k in live]]
-    assert torch.equal(full, got["persistent"][1])
-
-
 def test_split_dec_self_attn(G):
     from gram_amd import _lib
     from gram_amd.model.gram import relative_position_bucket
