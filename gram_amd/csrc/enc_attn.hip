@@ -138,6 +138,11 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const p16* __restrict__ q
       }
     }
 
+  // Every wave has read its K fragments: the K tiles' LDS is free from here on -- each wave stages its 32 output rows there at the end,
+  // so that the rows leave as whole 128 * S-byte segments (below).  (Waves past L left before the first barrier-counted instruction of
+  // this kind; s_barrier counts the waves that are still alive.)
+  __syncthreads();
+
   // bias + mask, row maximum over keys for this lane's query column(s)
   float mxq[2], l[2] = {0.f, 0.f};
 #pragma unroll
@@ -223,32 +228,48 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const p16* __restrict__ q
     }
   }
 
+  // Output: a lane holds 4 consecutive dims of ONE query per (nt, mt) -- stored from the registers that is 8 B per lane and piece in
+  // 32-byte pieces of 16 different rows per instruction, which costs the memory system twice what the same bytes cost as whole lines
+  // (profiles/r03r_enc_attn_ablation.txt: 4.7 ms with the stores, 3.5 without).  The wave's 32 rows x (128 * S) bytes -- one head's
+  // slice of the O GEMM's A operand, contiguous per row -- go through its 8 * S KB of the (dead) K tiles instead and leave as 16 B per
+  // lane, four (S = 2) or eight whole row segments per instruction.  Chunks are XOR-swizzled by the row: conflict-free both ways.
+  constexpr int RB = 128 * S, CPR = RB / 16;  // bytes and 16-B chunks per staged row
+  char* stage = ks + wave * (32 * RB);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     float lt = l[nt];
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
     const float inv_l = 1.f / lt;
-    const int query = q0 + 16 * nt + c;
-    p16* orow = out + ((size_t)p * L + query) * inner * S;  // (S == 2: the O GEMM's interleaved A operand, [rows][2 * inner])
+    const int ql = 16 * nt + c;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const f32x4 v = o[mt][nt] * inv_l;
-      const int n = h * 64 + 16 * mt + 4 * g;
       if constexpr (S == 2) {
+        // the head's 256 B of an interleaved row: [dims 0..31: piece 0 | piece 1][dims 32..63: piece 0 | piece 1]
         uint2 hi, lo;
         split2x4(v, hi, lo);
-        if (!(GRAM_ENC_ABL & 32) || hi.x == 0x12345678u) {
-          *reinterpret_cast<uint2*>(orow + inter_off(n, 0)) = hi;
-          *reinterpret_cast<uint2*>(orow + inter_off(n, 1)) = lo;
-        }
+        const int ch = (mt >> 1) * 8 + (mt & 1) * 2 + (g >> 1);  // 16-B chunk of piece 0; piece 1 sits 4 chunks on
+        *reinterpret_cast<uint2*>(stage + ql * RB + (((ch) ^ (ql & 15)) << 4) + (g & 1) * 8) = hi;
+        *reinterpret_cast<uint2*>(stage + ql * RB + (((ch + 4) ^ (ql & 15)) << 4) + (g & 1) * 8) = lo;
       } else {
         p16x4 r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) r[j] = (p16)v[j];
-        *reinterpret_cast<p16x4*>(orow + n) = r;
+        const int ch = 2 * mt + (g >> 1);
+        *reinterpret_cast<p16x4*>(stage + ql * RB + ((ch ^ (ql & 7)) << 4) + (g & 1) * 8) = r;
       }
     }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  char* obase = reinterpret_cast<char*>(out) + (((size_t)p * L + q0) * inner * S + (size_t)h * 64 * S) * sizeof(p16);
+#pragma unroll
+  for (int it = 0; it < RB / 32; ++it) {
+    const int row = it * (64 / CPR) + lane / CPR, chunk = lane % CPR;
+    const uint4 val = *reinterpret_cast<const uint4*>(stage + row * RB + ((chunk ^ (row & (CPR - 1))) << 4));
+    if (!(GRAM_ENC_ABL & 32) || val.x == 0x12345678u)
+      *reinterpret_cast<uint4*>(obase + (size_t)row * inner * S * sizeof(p16) + chunk * 16) = val;
   }
 }
 
