@@ -64,7 +64,8 @@ class LiveRows(C.Structure):
 class BeamState(C.Structure):
     _fields_ = [("B", i32), ("K", i32), ("Tmax", i32), ("length_penalty", f32), ("eos", i32), ("pad", i32),
                 ("tokens", vp), ("node", vp), ("beam_scores", vp), ("seq", vp), ("anc", vp), ("done", vp),
-                ("n_hyps", vp), ("hyp_score", vp), ("worst", vp), ("hyp_len", vp), ("hyp_tok", vp), ("error", vp)]
+                ("n_hyps", vp), ("hyp_score", vp), ("worst", vp), ("hyp_len", vp), ("hyp_tok", vp), ("error", vp),
+                ("cand_logits", vp), ("cand_logits_users", i32), ("cand_logits_stride", i64)]
 
 
 class Split(C.Structure):

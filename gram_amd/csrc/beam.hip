@@ -110,6 +110,85 @@ __global__ void beam_init_kernel(gram_beam_state_t st, gram_trie_t tr, int start
   st.node[r] = e < 0 ? -1 : tr.child_node[e];
 }
 
+// h[row] . E[tok] on 8 lanes (sub = lane & 7): the same sums in the same order wherever a candidate is computed -- inside the search
+// step's workgroup or, for a handful of users, by sparse_logits_kernel's many workgroups (launch_beam_step)
+__device__ __forceinline__ float sparse_dot(bool act, int lr, int tok, int sub, const p16* __restrict__ hd, const p16* __restrict__ emb,
+                                            const float* __restrict__ emb32, int d, int pieces) {
+  const int per = d >> 3;  // elements per lane
+    float acc = 0.f;
+    if (act && emb32) {
+      // two-piece mode (gram_split_t): h = fp32 sum of its pieces (smallest first; the row is interleaved, [2 d]), E = the fp32 lm_head row
+      const p16* hrow = hd + (size_t)lr * d * pieces;
+      const int c0 = sub * per;
+      auto hoff = [&](int n, int pc) { return pieces == 2 ? inter_off(n, pc) : n; };
+      const f32x4* ep = reinterpret_cast<const f32x4*>(emb32 + (size_t)tok * d + sub * per);
+      int i = 0;
+      if (pieces <= 2) {
+        // 32 elements per lane and trip, every load of the trip in flight together (one 8-element step per trip is a dependent
+        // round trip each: 12 of them per candidate at d = 768); same sums in the same order as the loop below
+        for (; i + 32 <= per; i += 32) {
+          p16x8 hb0[4], hb1[4];
+          f32x4 ev[8];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            hb0[u] = ld_global_b128(hrow + hoff(c0 + i + 8 * u, 0));
+            hb1[u] = pieces == 2 ? ld_global_b128(hrow + hoff(c0 + i + 8 * u, 1)) : zero_bf16x8();
+            ev[2 * u] = ep[(i >> 2) + 2 * u];
+            ev[2 * u + 1] = ep[(i >> 2) + 2 * u + 1];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float hv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = pieces == 2 ? (0.f + (float)hb1[u][e]) + (float)hb0[u][e] : 0.f + (float)hb0[u][e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += hv[e] * ev[2 * u][e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += hv[4 + e] * ev[2 * u + 1][e];
+          }
+        }
+      }
+      for (; i < per; i += 8) {
+        float hv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int pc = pieces - 1; pc >= 0; --pc) {
+          const p16x8 hb = ld_global_b128(hrow + hoff(c0 + i, pc));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hv[e] += (float)hb[e];
+        }
+        const f32x4 e0 = ep[i >> 2], e1 = ep[(i >> 2) + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += hv[e] * e0[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += hv[4 + e] * e1[e];
+      }
+    } else if (act) {
+      const p16* hp = hd + (size_t)lr * d + sub * per;
+      const p16* ep = emb + (size_t)tok * d + sub * per;
+      int i = 0;
+      for (; i + 32 <= per; i += 32) {  // 8 loads in flight per lane (one load pair per iteration is a dependent round trip each)
+        p16x8 hv[4], ev[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          hv[u] = ld_global_b128(hp + i + 8 * u);
+          ev[u] = ld_global_b128(ep + i + 8 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc += (float)hv[u][e] * (float)ev[u][e];  // same order as the scalar loop
+      }
+      for (; i < per; i += 8) {
+        const p16x8 hv = ld_global_b128(hp + i), ev = ld_global_b128(ep + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)hv[e] * (float)ev[e];
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    return acc;
+  }
+
 // NTHR threads per workgroup (= per user): 256 for batches that fill the chip with workgroups; 1 024 for small batches, where one user's
 // sparse logits (a trip computes NTHR / 4 candidates' dot products, each on its 8 lanes) and sort stages are the step's latency
 template <int NTHR>
@@ -117,7 +196,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
                                                         const float* __restrict__ lse, int V, int cur_len, int nc_max, int rows_per_user,
                                                         const p16* __restrict__ hd, const p16* __restrict__ emb, int d,
                                                         const int32_t* __restrict__ rowpos, int pieces,
-                                                        const float* __restrict__ emb32) {
+                                                        const float* __restrict__ emb32, const float* __restrict__ pre) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [nc_max]
   float* s_log = reinterpret_cast<float*>(keys + nc_max);                   // [nc_max / K] shared step-0 logits
@@ -176,7 +255,6 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
     const int sub = tid & 7, grp = tid >> 3;
     const bool shared0 = rows_per_user == 1;  // step 0: all K beams sit on the same node and the same row
     const int nuniq = shared0 ? s_pre[1] : C;
-    const int per = d >> 3;                   // elements per lane
     // (beam, token) of every candidate first, all threads at once, parked in the candidate's key slot: the dot products below then
     // start from LDS instead of a node -> edge -> token chain of global loads per batch
     for (int ci = tid; ci < nuniq; ci += NTHR) {
@@ -187,80 +265,9 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
       keys[ci] = ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)(uint32_t)tok;
     }
     __syncthreads();
-    // h[row] . E[tok] on 8 lanes (same sums in the same order whichever trip a candidate falls into)
-    auto dot = [&](bool act, int lr, int tok) -> float {
-      float acc = 0.f;
-      if (act && emb32) {
-        // two-piece mode (gram_split_t): h = fp32 sum of its pieces (smallest first; the row is interleaved, [2 d]), E = the fp32 lm_head row
-        const p16* hrow = hd + (size_t)lr * d * pieces;
-        const int c0 = sub * per;
-        auto hoff = [&](int n, int pc) { return pieces == 2 ? inter_off(n, pc) : n; };
-        const f32x4* ep = reinterpret_cast<const f32x4*>(emb32 + (size_t)tok * d + sub * per);
-        int i = 0;
-        if (pieces <= 2) {
-          // 32 elements per lane and trip, every load of the trip in flight together (one 8-element step per trip is a dependent
-          // round trip each: 12 of them per candidate at d = 768); same sums in the same order as the loop below
-          for (; i + 32 <= per; i += 32) {
-            p16x8 hb0[4], hb1[4];
-            f32x4 ev[8];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              hb0[u] = ld_global_b128(hrow + hoff(c0 + i + 8 * u, 0));
-              hb1[u] = pieces == 2 ? ld_global_b128(hrow + hoff(c0 + i + 8 * u, 1)) : zero_bf16x8();
-              ev[2 * u] = ep[(i >> 2) + 2 * u];
-              ev[2 * u + 1] = ep[(i >> 2) + 2 * u + 1];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              float hv[8];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) hv[e] = pieces == 2 ? (0.f + (float)hb1[u][e]) + (float)hb0[u][e] : 0.f + (float)hb0[u][e];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc += hv[e] * ev[2 * u][e];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc += hv[4 + e] * ev[2 * u + 1][e];
-            }
-          }
-        }
-        for (; i < per; i += 8) {
-          float hv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          for (int pc = pieces - 1; pc >= 0; --pc) {
-            const p16x8 hb = ld_global_b128(hrow + hoff(c0 + i, pc));
-#pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] += (float)hb[e];
-          }
-          const f32x4 e0 = ep[i >> 2], e1 = ep[(i >> 2) + 1];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc += hv[e] * e0[e];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc += hv[4 + e] * e1[e];
-        }
-      } else if (act) {
-        const p16* hp = hd + (size_t)lr * d + sub * per;
-        const p16* ep = emb + (size_t)tok * d + sub * per;
-        int i = 0;
-        for (; i + 32 <= per; i += 32) {  // 8 loads in flight per lane (one load pair per iteration is a dependent round trip each)
-          p16x8 hv[4], ev[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            hv[u] = ld_global_b128(hp + i + 8 * u);
-            ev[u] = ld_global_b128(ep + i + 8 * u);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += (float)hv[u][e] * (float)ev[u][e];  // same order as the scalar loop
-        }
-        for (; i < per; i += 8) {
-          const p16x8 hv = ld_global_b128(hp + i), ev = ld_global_b128(ep + i);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc += (float)hv[e] * (float)ev[e];
-        }
-      }
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      acc += __shfl_xor(acc, 4, 64);
-      return acc;
+    auto dot = [&](bool act, int lr, int tok, int ci) -> float {
+      if (pre) return act ? pre[(size_t)b * nc_max + ci] : 0.f;  // (computed by sparse_logits_kernel: the same function, the same bits)
+      return sparse_dot(act, lr, tok, sub, hd, emb, emb32, d, pieces);
     };
     // two candidates per 8-lane group and trip (NTHR / 4 per workgroup): their loads are independent and overlap
     constexpr int NG = NTHR / 8;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
       }
       float acc2[2];
 #pragma unroll
-      for (int w = 0; w < 2; ++w) acc2[w] = dot(act2[w], lr2[w], tok2[w]);
+      for (int w = 0; w < 2; ++w) acc2[w] = dot(act2[w], lr2[w], tok2[w], ci2[w]);
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
         if (act2[w] && sub == 0) {
@@ -484,6 +491,53 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
     st.tokens[row0 + tid] = sel_tok[tid];
     st.node[row0 + tid] = sel_node[tid];
   }
+}
+
+// The sparse logits of a search step, computed by MANY workgroups (a handful of users: beam_step_kernel's one workgroup per user pulls
+// up to K * fan-out fp32 lm_head rows -- 15 MB at K = 20, fan-out 255 -- through ONE CU, 70 us on average and up to 290 us of a one-user
+// step).  Workgroup (chunk, user) recomputes the user's candidate list exactly as beam_step_kernel does (beams in order, each beam's
+// Trie children in token order) and writes h . E[tok] of candidates [32 chunk, 32 chunk + 32) to out[user][candidate]; the search
+// step then reads them instead of computing them -- sparse_dot either way: the same bits.
+__global__ __launch_bounds__(256) void sparse_logits_kernel(gram_beam_state_t st, gram_trie_t tr, int nc_max, int rows_per_user,
+                                                            const p16* __restrict__ hd, const p16* __restrict__ emb, int d,
+                                                            const int32_t* __restrict__ rowpos, int pieces,
+                                                            const float* __restrict__ emb32, float* __restrict__ out) {
+  __shared__ int s_pre[GRAM_MAX_BEAMS + 1], s_off[GRAM_MAX_BEAMS], s_cnt[GRAM_MAX_BEAMS], s_lr[GRAM_MAX_BEAMS];
+  const int b = blockIdx.y, tid = threadIdx.x, K = st.K, row0 = b * K;
+  if (st.done[b]) return;
+  if (tid < K) {
+    const int nd = st.node[row0 + tid];
+    int o0 = 0, cnt = 0;
+    if (nd >= 0) {
+      o0 = tr.child_off[nd];
+      cnt = tr.child_off[nd + 1] - o0;
+    }
+    s_off[tid] = o0;
+    s_cnt[tid] = cnt;
+    s_lr[tid] = rowpos ? rowpos[row0 + tid] : row0 + tid;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int k = 0; k < K; ++k) {
+      s_pre[k] = acc;
+      acc += s_cnt[k];
+    }
+    s_pre[K] = acc;
+  }
+  __syncthreads();
+  const bool shared0 = rows_per_user == 1;
+  const int nuniq = shared0 ? s_pre[1] : (s_pre[K] <= nc_max ? s_pre[K] : 0);  // (more than nc_max: the search step flags it)
+  const int ci = blockIdx.x * 32 + (tid >> 3), sub = tid & 7;
+  const bool act = ci < nuniq;
+  int k = 0, tok = 0;
+  if (act) {
+    if (!shared0)
+      while (s_pre[k + 1] <= ci) ++k;
+    tok = tr.child_tok[s_off[k] + (ci - s_pre[k])];
+  }
+  const float v = sparse_dot(act, shared0 ? b : s_lr[k], tok, sub, hd, emb, emb32, d, pieces);
+  if (act && sub == 0) out[(size_t)b * nc_max + ci] = v;
 }
 
 // Live rows of the coming decode step: a beam that left the Trie (its hypothesis went to the heap at EOS and HF refilled
@@ -707,12 +761,24 @@ static int launch_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, 
   // few users: one workgroup per user leaves the chip empty and the step is that workgroup's latency -> 1 024 threads per user
   // (same per-candidate arithmetic, same total order of the keys: identical results; GRAM_BEAM_WIDE_MAXB: A/B hook, 0 = never)
   static const int wide_max_b = getenv("GRAM_BEAM_WIDE_MAXB") ? atoi(getenv("GRAM_BEAM_WIDE_MAXB")) : 128;
+  // a handful of users: the sparse logits by their own kernel over many CUs (sparse_logits_kernel), the search step reads them
+  // (gram_beam_state_t.cand_logits: caller-provided scratch; GRAM_BEAM_PRE_MAXB: A/B hook, 0 = never)
+  static const int pre_max_b = getenv("GRAM_BEAM_PRE_MAXB") ? atoi(getenv("GRAM_BEAM_PRE_MAXB")) : 16;
+  const float* pre = nullptr;
+  if (!logits && st->cand_logits && st->B <= pre_max_b && st->B <= st->cand_logits_users && (long long)nc <= st->cand_logits_stride) {
+    const int chunks = (int)((need + 31) / 32);
+    hipLaunchKernelGGL(sparse_logits_kernel, dim3(chunks, st->B), dim3(256), 0, (hipStream_t)stream, *st, *tr, nc,
+                       rows_per_user, (const p16*)hd, (const p16*)emb, d, rowpos, pieces, emb32, st->cand_logits);
+    GRAM_CHECK_LAUNCH();
+    pre = st->cand_logits;
+  }
+  const int nc_arg = nc;
   if (st->B <= wide_max_b)
-    hipLaunchKernelGGL(beam_step_kernel<1024>, dim3(st->B), dim3(1024), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc,
-                       rows_per_user, (const p16*)hd, (const p16*)emb, d, rowpos, pieces, emb32);
+    hipLaunchKernelGGL(beam_step_kernel<1024>, dim3(st->B), dim3(1024), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc_arg,
+                       rows_per_user, (const p16*)hd, (const p16*)emb, d, rowpos, pieces, emb32, pre);
   else
-    hipLaunchKernelGGL(beam_step_kernel<256>, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc,
-                       rows_per_user, (const p16*)hd, (const p16*)emb, d, rowpos, pieces, emb32);
+    hipLaunchKernelGGL(beam_step_kernel<256>, dim3(st->B), dim3(256), smem, (hipStream_t)stream, *st, *tr, logits, lse, V, cur_len, nc_arg,
+                       rows_per_user, (const p16*)hd, (const p16*)emb, d, rowpos, pieces, emb32, pre);
   GRAM_CHECK_LAUNCH();
   return 0;
 }

@@ -60,7 +60,7 @@ namespace {
 // In-kernel clock of the ping-pong GEMM (MI355X_MICROARCH.md, DVFS item 6) -- a DIAGNOSTIC, off unless gram_prof_pp_clock_enable(1)
 // (bench.py switches it on for its timed region): every workgroup then stamps s_memtime (shader cycles) and s_memrealtime (100-MHz
 // ticks) around its tile loop and adds the two differences to these sums -- two atomics per workgroup and launch; switched off, the
-// kernel takes one wave-uniform branch around each.
+// workgroup still reads the two counters (see the kernel) and skips the atomics.
 // gram_prof_pp_clock() = sum / sum x 0.1 GHz: the time-weighted clock the chip held inside these kernels since the last reset (the MFMA
 // peak it can be priced against: the chip is power-limited in them).
 __device__ unsigned long long g_pp_clk[2];
@@ -671,6 +671,17 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const p16* __restrict_
     abase += 256;
     i_slot = i_slot + 1 == NS ? 0 : i_slot + 1;
   };
+  // fp32-residual epilogue: this lane's four residual values (and its row's factor of the 16-bit copy) are requested HERE, by LDS-DMA
+  // into a patch behind the ring, as the wave's OLDEST vector-memory operations -- every counted wait below covers them -- instead of by
+  // a load in the epilogue, where a one-user decode step (a chain of ~600 such launches) paid an exposed HBM round trip per launch
+  constexpr int RES_OFF = NS * SB;  // [MT][64 lanes x 16 B] residuals, then [MT][64 x 4 B] row factors
+  if constexpr (EPI == GRAM_EPI_F32_ADD) {
+    if (consumer) {
+      const int mr = min(m0 + wave * 16 + r16, M - 1);
+      dma16_asm(lds0 + RES_OFF + wave * 1024, (uint32_t)mr * (uint32_t)ep.ldc * 4u + (uint32_t)(n0 + 4 * g) * 4u, reinterpret_cast<const char*>(ep.C));
+      if (ep.xs_in && ep.xb_out) dma4_asm(lds0 + RES_OFF + MT * 1024 + wave * 256, (uint32_t)mr * 4u, reinterpret_cast<const char*>(ep.xs_in));
+    }
+  }
   const int npro = min(NS - 1, nst);
   for (int st = 0; st < npro; ++st) issue();
 
@@ -747,10 +758,10 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const p16* __restrict_
     if (row_ok) {
       f32x4* pc = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.C) + (size_t)m * ep.ldc + n);
       f32x4 val = acc * ep.out_scale;
-      val += *pc;
+      val += *reinterpret_cast<const f32x4*>(smem + RES_OFF + wave * 1024 + lane * 16);  // (landed: the loop's last wait is vmcnt(0))
       *pc = val;
       if (ep.xb_out) {
-        f32x4 rem = ep.xs_in ? val * ep.xs_in[m] : val;
+        f32x4 rem = ep.xs_in ? val * *reinterpret_cast<const float*>(smem + RES_OFF + MT * 1024 + wave * 256 + lane * 4) : val;
         p16* xrow = ep.xb_out + (size_t)m * ep.ldc * ep.split;
         for (int p = 0; p < ep.split; ++p) {
           const uint2 pk = pack_bf16x4(rem);
@@ -793,7 +804,9 @@ bool stream_enabled() { return stream_max_m() > 0; }
 
 template <int EPI, int MT, bool X3>
 int launch_stream_mt(const void* A, const void* W, int M, int N, int K, int lda, EpiArgs ep, hipStream_t st) {
-  constexpr int smem = StreamCfg<MT>::NS * StreamCfg<MT>::SB;
+  // (+ the fp32-residual epilogue's prefetch patch: 1 KiB of residuals and 256 B of row factors per consumer wave)
+  constexpr int smem = StreamCfg<MT>::NS * StreamCfg<MT>::SB + (EPI == GRAM_EPI_F32_ADD ? MT * 1280 : 0);
+  static_assert(smem <= 160 * 1024, "ring + residual patch must fit the LDS");
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<EPI, MT, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1132,6 +1145,8 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
         f32x4 val = *reinterpret_cast<const f32x4*>(patch + row * 256 + ((c ^ row) * 16)) * o.scale;
         const int mr = j * 16 + row;
         float ssq = 0.f;
+        // (fetched by ALL lanes, outside the M-tail predicate below: a cross-lane read from a lane that the predicate switched off returns garbage)
+        const float xs_row = __shfl(xsl, p * 16 + it * 4 + (lane >> 4), 64);
         if (mr < o.rows && (!(GRAM_PP_ABL & 16) || o.rows < -12345)) {
           f32x4* pc = reinterpret_cast<f32x4*>(o.c + ((uint32_t)mr * o.ldc_b + c * 16));
           if constexpr (EPI == GRAM_EPI_F32_ADD) val += res[p * 4 + it];
@@ -1139,7 +1154,7 @@ __device__ __forceinline__ void pp_store_tile_f32(f32x4 (&acc)[4][8], char* patc
           //                                            bytes a residual stream kept as its two pieces only would move: DESIGN.md 9.1)
           if constexpr (EPI == GRAM_EPI_F32_ADD) {
             if (o.xb) {
-              const f32x4 xv = val * __shfl(xsl, p * 16 + it * 4 + (lane >> 4), 64);  // the 16-bit copy carries the row's power-of-two factor
+              const f32x4 xv = val * xs_row;  // the 16-bit copy carries the row's power-of-two factor
               if (o.split == 2) {
                 // interleaved copy (lanes 0..7 hold block 0 of the wave's 64 columns, lanes 8..15 block 1; a block = piece 0's 64 B, then
                 // piece 1's): lanes c and c ^ 1 swap one piece each, so that the even lane stores 16 B of piece 0 (columns 4c .. 4c + 7)
@@ -1787,11 +1802,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const p16* __restrict__
   zero_half(0);
   zero_half(1);
   abl_loop = true;
-  unsigned long long clk_t0 = 0ull, clk_r0 = 0ull;
-  if (clk_on) {
-    clk_t0 = __builtin_amdgcn_s_memtime();
-    clk_r0 = __builtin_amdgcn_s_memrealtime();
-  }
+  // The two stamps are read UNCONDITIONALLY (two scalar instructions per workgroup and launch); only the atomics at the end are behind
+  // gram_prof_pp_clock_enable.  With the reads themselves inside `if (clk_on)` the fp32-residual instantiations of this kernel returned
+  // wrong tiles intermittently -- flag on or off -- while the kernel without any stamp and the kernel with unconditional ones are both
+  // clean over tens of thousands of randomized runs (tests/stress_gemm_pp*.py, profiles/r04i_pp_clock_flag_race.txt); the difference
+  // is in hipcc's code for the loop entry (spill placement), its cause was not found.  tests/test_gpu_kernels.py runs the screens.
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   if constexpr (INSL) {
     const float *rs_cur = nullptr, *rs_prev = nullptr;
     auto set_tile = [&]() {

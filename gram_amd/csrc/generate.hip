@@ -146,6 +146,10 @@ Workspace carve(const gram_model* m, void* ws, int B, int N, int L, int K, int T
   s.hyp_len = cv.take<int32_t>((int64_t)B * (K + 1));
   s.hyp_tok = cv.take<int32_t>((int64_t)B * (K + 1) * Tmax);
   s.error = cv.take<int32_t>(4);
+  // scratch of the small-batch sparse-logits kernel (gram_beam_state_t.cand_logits): 16 384 >= any K * max_fanout the search accepts
+  s.cand_logits_users = B < 16 ? B : 16;
+  s.cand_logits_stride = 16384;
+  s.cand_logits = cv.take<float>((int64_t)s.cand_logits_users * s.cand_logits_stride);
   w.live.rows = cv.take<int32_t>(R);
   w.live.rowpos = cv.take<int32_t>(R);
   w.live.users = cv.take<int32_t>(B);

@@ -255,6 +255,13 @@ typedef struct {
   int32_t* hyp_len;        /* [B][K+1]                                                   */
   int32_t* hyp_tok;        /* [B][K+1][Tmax]                                             */
   int32_t* error;          /* [1]        set non-zero on an impossible state              */
+  /* optional scratch (NULL / 0 = off): with B <= cand_logits_users (and <= 16) users a sparse search step computes its candidates'
+   * logits with a kernel of its own over many CUs before the per-user search kernel runs -- one workgroup per user pulls up to
+   * K * fan-out lm_head rows through ONE CU, most of a one-user step.  f32 [cand_logits_users][cand_logits_stride],
+   * cand_logits_stride >= the power of two >= K * max_fanout.  Same values either way. */
+  float* cand_logits;
+  int32_t cand_logits_users;
+  int64_t cand_logits_stride;
 } gram_beam_state_t;
 
 /* decoder_input_ids = [[start]]*B*K ; beam_scores = [0,-1e9,...] (HF 4.26 beam_search init). */

@@ -61,7 +61,8 @@ def gemm(A, W, epi, C_out=None, bank=None):
     return C_out
 
 
-def make_beam_state(B, K, Tmax, lp=1.0, device=DEV):
+def make_beam_state(B, K, Tmax, lp=1.0, device=DEV, cand_scratch=False):
+    """cand_scratch: also give the state the scratch of the small-batch sparse-logits kernel (gram_beam_state_t.cand_logits)"""
     R = B * K
     t = dict(
         tokens=torch.zeros(R, dtype=torch.int32, device=device), node=torch.zeros(R, dtype=torch.int32, device=device),
@@ -71,7 +72,11 @@ def make_beam_state(B, K, Tmax, lp=1.0, device=DEV):
         worst=torch.zeros(B, dtype=torch.float64, device=device), hyp_len=torch.zeros(B, K + 1, dtype=torch.int32, device=device),
         hyp_tok=torch.zeros(B, K + 1, Tmax, dtype=torch.int32, device=device), error=torch.zeros(4, dtype=torch.int32, device=device),
     )
-    st = _lib.BeamState(B=B, K=K, Tmax=Tmax, length_penalty=lp, eos=1, pad=0, **{k: v.data_ptr() for k, v in t.items()})
+    extra = {}
+    if cand_scratch:
+        t["cand_logits"] = torch.full((B, 16384), float("nan"), dtype=torch.float32, device=device)
+        extra = dict(cand_logits_users=B, cand_logits_stride=16384)
+    st = _lib.BeamState(B=B, K=K, Tmax=Tmax, length_penalty=lp, eos=1, pad=0, **{k: v.data_ptr() for k, v in t.items()}, **extra)
     return st, t
 
 

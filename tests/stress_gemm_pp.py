@@ -18,6 +18,7 @@ from tests import gpu_util as G  # noqa: E402
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     lib = _lib.load()
+    lib.gram_prof_pp_clock_enable(int(os.environ.get("STAMPS", "0")))  # the diagnostic clock stamps change the kernel's timing: screen both
     rng = random.Random(1234)
     t0, n_cases, n_runs = time.time(), 0, 0
     while time.time() - t0 < budget:
@@ -30,6 +31,7 @@ def main():
         A = torch.randn(M, K, generator=g).to(G.DEV).to(G.DT)
         W = (torch.randn(N, K, generator=g) * K ** -0.5).to(G.DEV).to(G.DT)
         rs = (torch.rand(M, generator=g) + 0.5).to(G.DEV)
+        xs = torch.pow(2.0, torch.randint(-6, 7, (M,), generator=g).float()).to(G.DEV) if rng.random() < 0.7 else None  # gram_norm_fusion_t.xs_in
         base = torch.randn(M, N, generator=g).to(G.DEV) if epi == _lib.EPI_F32_ADD else None
         f32 = epi in (_lib.EPI_F32_ADD, _lib.EPI_F32)
 
@@ -40,7 +42,7 @@ def main():
             if fused and epi == _lib.EPI_F32_ADD:
                 xb = torch.zeros(M, N, dtype=G.DT, device=G.DEV)
                 ss = torch.zeros(M, N // 64, dtype=torch.float32, device=G.DEV)
-                nf = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0)
+                nf = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0, 0, xs.data_ptr() if xs is not None else None, None)
                 extra = [xb, ss]
             elif fused and not f32:
                 nf = _lib.NormFusion(None, None, rs.data_ptr(), 0, K, 1e-6)

@@ -19,6 +19,7 @@ from tests import gpu_util as G  # noqa: E402
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     lib = _lib.load()
+    lib.gram_prof_pp_clock_enable(int(os.environ.get("STAMPS", "0")))  # the diagnostic clock stamps change the kernel's timing: screen both
     rng = random.Random(4321)
     t0, n_cases, n_runs = time.time(), 0, 0
     while time.time() - t0 < budget:
@@ -33,6 +34,8 @@ def main():
         W = (torch.randn(N, 2 * K, generator=g, device=G.DEV) * K ** -0.5).to(G.DT)
         rs = torch.rand(M, generator=g, device=G.DEV) + 0.5
         base = torch.randn(M, N, generator=g, device=G.DEV) if epi == _lib.EPI_F32_ADD else None
+        # the row factors of the 16-bit copy (gram_norm_fusion_t.xs_in: a power of two per row), as every generate() passes them
+        xs = torch.pow(2.0, torch.randint(-6, 7, (M,), generator=g, device=G.DEV).float()) if rng.random() < 0.7 else None
 
         def run(v):
             lib.gram_debug_set_gemm_variant(v)
@@ -41,7 +44,7 @@ def main():
                 C = base.clone()
                 xb = torch.zeros(M, 2 * N, dtype=G.DT, device=G.DEV)
                 ss = torch.zeros(M, N // 64, dtype=torch.float32, device=G.DEV)
-                nf = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0, 0) if fused else None
+                nf = _lib.NormFusion(xb.data_ptr(), ss.data_ptr(), None, 0, 0, 0.0, 0, xs.data_ptr() if xs is not None else None, None) if fused else None
                 extra = [xb, ss]
                 sp = _lib.Split(2, 0, 0, 0, 0.0)
                 ldc = N

@@ -30,7 +30,7 @@ def test_abi_version_and_struct_sizes():
     # field layout sanity (pointer + int32 packing as in the C header)
     assert ctypes.sizeof(_lib.KVBank) == 48
     assert ctypes.sizeof(_lib.Trie) == 40
-    assert ctypes.sizeof(_lib.BeamState) == 24 + 12 * 8
+    assert ctypes.sizeof(_lib.BeamState) == 24 + 12 * 8 + 8 + 8 + 8  # (+ cand_logits, its user count (padded), its stride)
     assert ctypes.sizeof(_lib.ModelDesc) == 48 + 7 * 8 + 15 * 8 + 8 + 16 + 8
     assert ctypes.sizeof(_lib.Split) == 32
     assert lib.gram_piece_format() in (0, 1)

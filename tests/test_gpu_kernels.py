@@ -198,6 +198,22 @@ def test_gemm_64_row_tiles_match_128(G, M, N, K):
             assert torch.equal(outs[1][key], outs[v][key]), (v, key)
 
 
+@pytest.mark.parametrize("script", ["stress_gemm_pp.py", "stress_gemm_pp_x3.py"])
+@pytest.mark.parametrize("stamps", ["0", "1"])
+def test_ping_pong_gemm_race_screen(G, script, stamps):
+    """The randomized race screens of the persistent ping-pong GEMM (random shapes x epilogues against the 256x128-tile kernel, bit for
+    bit, three runs each) for a few seconds inside the suite, with the diagnostic clock stamps off and on: round 4 shipped, for a few
+    commits, a build whose fp32-residual instantiation returned wrong tiles intermittently (profiles/r04i_pp_clock_flag_race.txt) and
+    only ONE fixed-shape test noticed."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", script), "8"], cwd=root, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, STAMPS=stamps))
+    assert p.returncode == 0 and "MISMATCH" not in p.stdout, p.stdout[-600:] + p.stderr[-600:]
+
+
 def test_f16_alias_is_the_same_entry_point(G):
     """gram_gemm_f16 (gram_hip.h: the alias a maintainer should bind) runs gram_gemm_bf16's kernel in the IEEE-half build."""
     if not G.F16:
@@ -626,7 +642,8 @@ def test_greedy_step_bit_exact_vs_oracle(G):
 
 def test_beam_step_sparse_equals_dense(G):
     """gram_beam_step_sparse (logits of the allowed tokens recomputed in the kernel from hidden . lm_head, LSE from
-    the fused lm_head epilogue, logits never stored) selects exactly what the dense path selects."""
+    the fused lm_head epilogue, logits never stored) selects exactly what the dense path selects -- and with the small-batch scratch
+    (gram_beam_state_t.cand_logits: the sparse logits by a kernel of their own over many CUs) the very same bits."""
     import os
     from gram_amd import _lib
     from gram_amd.utils import generation_trie as gt
@@ -640,9 +657,9 @@ def test_beam_step_sparse_equals_dense(G):
     emb = G.bf(torch.randn(V, d, generator=g))
     L_ = G.lib()
     results = []
-    for mode in ("dense", "sparse"):
+    for mode in ("dense", "sparse", "sparse_pre"):
         g2 = torch.Generator().manual_seed(17)
-        st, keep = G.make_beam_state(B, K, max_length)
+        st, keep = G.make_beam_state(B, K, max_length, cand_scratch=mode == "sparse_pre")
         ctrie, keep2 = flat.to_device(torch.device(G.DEV))
         _lib.check(L_.gram_beam_init(C.byref(st), C.byref(ctrie), 0, G.stream()), "init")
         for t in range(max_length - 1):
@@ -670,6 +687,7 @@ def test_beam_step_sparse_equals_dense(G):
         results.append((seqs.cpu(), scores.cpu()))
     assert results[0][0].tolist() == results[1][0].tolist()
     assert torch.allclose(results[0][1], results[1][1], atol=2e-5)
+    assert torch.equal(results[1][0], results[2][0]) and torch.equal(results[1][1], results[2][1])
 
 
 @pytest.mark.parametrize("M", [300, 33000])  # 128x128 direct epilogue / persistent 256x256 row-contiguous epilogue
