@@ -17,6 +17,12 @@ and inputs:
     python tests/precision_population.py --users 4096 --chunk 256 --modes f16x3,f16 --out gpurun_out/precision.json
     python tests/precision_population.py --users 2048 --sweep f16x3      # every stage at one piece, the rest at two
 
+``--outliers F`` gives the model the residual stream of a TRAINED T5 (none exists offline): a few feature dimensions carry values F times
+the ordinary ones from the embedding on and are fed by every sublayer's output projection, while the layer norms' gains shrink them
+back (gain / F on those dimensions, and all gains x the factor by which the outliers inflate a row's rms) -- so the stream leaves the
+IEEE-half range for large F, its rms is dominated by the outliers, and the information sits in dimensions far below the rms: the case
+the per-row power-of-two factors of the 16-bit copy exist for.
+
 ``--sharpen F`` multiplies every attention q projection by F: at T5's random init the attention logits are ~N(0,1)
 and every query averages ~140 keys, which washes the encoder out of the scores (all users get nearly the same
 beams); F = 4 gives peaky attention (a few keys per query), i.e. scores that depend on the passages as a trained
@@ -43,7 +49,33 @@ def _strip(row):
     return tuple(int(t) for t in row if int(t) not in (0, 1))
 
 
-def build(backbone, seed, sharpen, dev):
+OUTLIER_DIMS = (7, 200, 450, 701)
+
+
+def add_outlier_features(sd, oc, F):
+    """In place: see --outliers in the module docstring."""
+    dims = [d for d in OUTLIER_DIMS if d < oc.d_model]
+    infl = float(np.sqrt(1.0 + len(dims) * F * F / oc.d_model))  # how much the outliers inflate a row's rms
+    done = set()
+    for k in list(sd):
+        v = sd[k]
+        if id(v) in done:
+            continue
+        if k.endswith("shared.weight") or k.endswith("embed_tokens.weight"):
+            v[:, dims] *= F
+        elif k.endswith(".o.weight") or k.endswith(".wo.weight"):      # [d_model][inner | d_ff]: the rows that write the outlier features
+            v[dims, :] *= F
+        elif k.endswith("layer_norm.weight"):
+            v *= infl
+            v[dims] /= F
+        elif k == "lm_head.weight":
+            v *= oc.d_model ** -0.5  # untied (see build): the scale the tied head gets from gram_t5.py:249-252, so the logits stay O(1)
+        else:
+            continue
+        done.add(id(v))
+
+
+def build(backbone, seed, sharpen, dev, outliers=0.0):
     import gram_amd
     from oracle import gram_oracle as O
 
@@ -52,13 +84,24 @@ def build(backbone, seed, sharpen, dev):
                             max_item_num=5)
     else:
         oc = O.OracleConfig.named(backbone)
+    if outliers:  # an untied lm_head: the logits keep their ordinary scale (a tied one would read the outlier columns of the table)
+        import dataclasses
+        oc = dataclasses.replace(oc, tie_word_embeddings=False)
     gc = gram_amd.T5Config(vocab_size=oc.vocab_size, d_model=oc.d_model, d_ff=oc.d_ff, num_layers=oc.num_layers,
-                           num_decoder_layers=oc.num_decoder_layers, num_heads=oc.num_heads, max_item_num=oc.max_item_num)
+                           num_decoder_layers=oc.num_decoder_layers, num_heads=oc.num_heads, max_item_num=oc.max_item_num,
+                           tie_word_embeddings=oc.tie_word_embeddings)
     sd = O.init_state_dict(oc, seed)
     if sharpen != 1.0:
         for k in sd:
             if k.endswith(".q.weight"):
                 sd[k] = sd[k] * sharpen
+    if outliers:
+        sd = {k: v for k, v in sd.items()}
+        uniq = {}
+        for k, v in sd.items():  # clone once per distinct tensor: the tied tables stay tied
+            uniq.setdefault(id(v), v.clone())
+            sd[k] = uniq[id(v)]
+        add_outlier_features(sd, oc, outliers)
     model = gram_amd.create_model("gram", gc)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
@@ -144,11 +187,11 @@ def sweep_modes(base, pieces):
 
 
 def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("f16x3",), seed=2023, sharpen=1.0, N=3, L=128, K=20,
-        dev="cuda:0", log=print, n_items=0, ragged=False):
+        dev="cuda:0", log=print, n_items=0, ragged=False, outliers=0.0):
     from gram_amd.utils import generation_trie as gt
     from oracle import gram_oracle as O
 
-    oc, sd, model = build(backbone, seed, sharpen, dev)
+    oc, sd, model = build(backbone, seed, sharpen, dev, outliers)
     if backbone == "tiny":
         g0 = torch.Generator().manual_seed(5)
         cands = sorted({tuple([0] + torch.randint(2, 60, (3,), generator=g0).tolist() + [1]) for _ in range(n_items or 400)})
@@ -204,7 +247,7 @@ def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("f16
     model.set_stage_pieces(None)
     return {
         "population": {"backbone": backbone, "dataset": dataset, "items": len(cands), "users": users, "N": N, "L": L, "K": K,
-                       "seed": seed, "q_sharpen": sharpen, "ragged_masks": bool(ragged), "gold_rank": "reference rank (user index mod 10)",
+                       "seed": seed, "q_sharpen": sharpen, "ragged_masks": bool(ragged), "outlier_features_x": outliers, "gold_rank": "reference rank (user index mod 10)",
                        "reference": "oracle/gram_oracle.py run with torch fp32 tensors on the GPU (rocBLAS fp32), HF-4.26 search on the host"},
         "modes": {m: summarise(a) for m, a in accs.items()},
     }
@@ -220,6 +263,7 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="ragged masks (valid lengths U[L/4, L], some passages fully padded)")
     ap.add_argument("--seed", type=int, default=2023)
     ap.add_argument("--sharpen", type=float, default=1.0)
+    ap.add_argument("--outliers", type=float, default=0.0, help="outlier features F times the ordinary ones (a trained T5's residual stream)")
     ap.add_argument("--beams", type=int, default=20)
     ap.add_argument("--out", default="")
     ap.add_argument("--sweep", default="", help="BASE mode: every stage at fewer pieces with the rest at BASE (per-stage sensitivity)")
@@ -228,7 +272,7 @@ def main():
     if a.sweep:
         import gram_amd
         modes = tuple(sweep_modes(a.sweep, gram_amd.GRAM._PIECES[a.sweep]))
-    res = run(a.users, a.chunk, a.backbone, a.dataset, modes, a.seed, a.sharpen, K=a.beams, ragged=a.ragged)
+    res = run(a.users, a.chunk, a.backbone, a.dataset, modes, a.seed, a.sharpen, K=a.beams, ragged=a.ragged, outliers=a.outliers)
     txt = json.dumps(res, indent=1)
     print(txt)
     if a.out:
