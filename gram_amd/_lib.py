@@ -13,12 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAM_LIB") or os.path.join(_HERE, "csrc", "libgram_hip.so")  # (GRAM_LIB: an A/B build of the same ABI)
 
 GRAM_MAX_BEAMS = 64
-GRAM_MAX_DEC_LEN = 32
+GRAM_MAX_DEC_LEN = 64
 GRAM_MAX_PASSAGE_LEN = 128
 EPI_BF16, EPI_BF16_RELU, EPI_F32_ADD, EPI_F32, EPI_KV_BANK = range(5)
 K_GEMM, K_ENC_ATTN, K_CROSS_ATTN, K_DEC_SELF_ATTN, K_ROWOPS, K_LSE, K_BEAM = range(7)
 E_ARG, E_WORKSPACE, E_BEAM, E_NONFINITE = -1, -2, -3, -4
-ABI_VERSION = 6
+ABI_VERSION = 7
 # two-piece mode (gram_hip.h, gram_split_t): 16-bit pieces per value -> MFMA products per product
 MAX_PIECES = 2
 SPLIT_NPROD = (0, 1, 3)

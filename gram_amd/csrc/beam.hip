@@ -199,13 +199,14 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
                                                         const float* __restrict__ emb32, const float* __restrict__ pre) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);  // [nc_max]
-  float* s_log = reinterpret_cast<float*>(keys + nc_max);                   // [nc_max / K] shared step-0 logits
+  float* s_log = reinterpret_cast<float*>(keys + nc_max);                   // [max_fanout, rounded up to 4] shared step-0 logits
+  // [K][Tmax] + [Tmax][K]: the advanced sequences / ancestor table on their way back to HBM (sized by the call, not by the maxima)
+  int* new_seq = reinterpret_cast<int*>(smem + (size_t)nc_max * 8 + ((size_t)tr.max_fanout * 4 + 15) / 16 * 16);
+  int* new_anc = new_seq + st.K * st.Tmax;
   __shared__ int s_pre[GRAM_MAX_BEAMS + 1];
   __shared__ int s_C, s_NC, s_isdone;
   __shared__ float sel_score[GRAM_MAX_BEAMS];
   __shared__ int sel_tok[GRAM_MAX_BEAMS], sel_par[GRAM_MAX_BEAMS], sel_node[GRAM_MAX_BEAMS];
-  __shared__ int new_seq[GRAM_MAX_BEAMS * GRAM_MAX_DEC_LEN];
-  __shared__ int new_anc[GRAM_MAX_DEC_LEN * GRAM_MAX_BEAMS];
   __shared__ int s_edge[2 * GRAM_MAX_BEAMS];
   __shared__ int s_off[GRAM_MAX_BEAMS], s_cnt[GRAM_MAX_BEAMS], s_lr[GRAM_MAX_BEAMS];
 
@@ -746,8 +747,8 @@ static int launch_beam_step(const gram_beam_state_t* st, const gram_trie_t* tr, 
   long long need = (long long)st->K * tr->max_fanout;
   int nc = 64;
   while (nc < need) nc <<= 1;
-  const size_t smem = (size_t)nc * 8 + ((size_t)tr->max_fanout * 4 + 15) / 16 * 16;
-  if (smem > 132 * 1024) return GRAM_E_ARG;
+  const size_t smem = (size_t)nc * 8 + ((size_t)tr->max_fanout * 4 + 15) / 16 * 16 + (size_t)2 * st->K * st->Tmax * 4;
+  if (smem > 152 * 1024) return GRAM_E_ARG;  // (+ ~3 KB of static arrays: the CU's 160 KB)
   static size_t attr_bytes = 0;
   if (smem > attr_bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,

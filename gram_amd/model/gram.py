@@ -337,14 +337,14 @@ class GRAM(nn.Module):
             w = torch.cat([sd[prefix + ".q.weight"], sd[prefix + ".k.weight"], sd[prefix + ".v.weight"]], 0).to(dev, torch.float32)
             return b16(w * sd[gname].to(dev, torch.float32)[None, :], stage) if fold else b16(w, stage)
 
-        # relative-bias tables: encoder [H][255] by (key - query + 127), decoder [H][32] by distance
+        # relative-bias tables: encoder [H][255] by (key - query + 127), decoder [H][GRAM_MAX_DEC_LEN] by distance
         nb, md = c.relative_attention_num_buckets, c.relative_attention_max_distance
         rel = torch.arange(-127, 128)
         enc_tab = sd["encoder.encoder.block.0.module.layer.0.SelfAttention.relative_attention_bias.weight"].cpu().float()
         enc_bias = enc_tab[relative_position_bucket(rel, True, nb, md)].t().contiguous()  # (H,255)
         dist = torch.arange(0, _lib.GRAM_MAX_DEC_LEN)
         dec_tab = sd["decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].cpu().float()
-        dec_bias = dec_tab[relative_position_bucket(-dist, False, nb, md)].t().contiguous()  # (H,32)
+        dec_bias = dec_tab[relative_position_bucket(-dist, False, nb, md)].t().contiguous()  # (H, GRAM_MAX_DEC_LEN)
 
         e = "encoder.encoder.block.{}.module.layer"
         dd = "decoder.block.{}.layer"
@@ -402,7 +402,7 @@ class GRAM(nn.Module):
         if need < 0:
             raise _lib.GramHipError(
                 f"unsupported problem size B={B} N={N} L={L} K={K} max_length={max_length} "
-                f"(N <= max_item_num+1, L <= 128, K <= 64, max_length <= 32)"
+                f"(N <= max_item_num+1, L <= 128, K <= 64, max_length <= {_lib.GRAM_MAX_DEC_LEN})"
             )
         dev = self._device()
         if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:

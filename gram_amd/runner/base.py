@@ -187,6 +187,41 @@ class BaseRunner:
             return int(model.max_users_per_call(n_slots, L, K, max_length, limit=4096))
         return 4096
 
+    def _rescore_unfinished(self, model, input_ids, attention_mask, seqs, scores, fn, K, ref_max_length, shape):
+        """Users of a batch decoded to the Trie's depth who have fewer than K finished hypotheses (a -inf score among their K rows:
+        only BeamSearchScorer.finalize's filler beams carry one), scored again with the reference's own max_length
+        (single_runner_gram.py:637: 50 for the "term" id type) -- HF keeps decoding such a user's -inf beams until max_length and
+        finalizes THOSE.  Everyone else's rows are what HF returns at either length (see _score_loader).  Which tokens a -inf
+        beam carries is torch.topk's choice among equal keys in the reference and "lowest flat index first" here; the finite rows, their
+        order and their scores do not depend on it."""
+        B = input_ids.shape[0]
+        unfinished = (~torch.isfinite(scores.view(B, K))).any(dim=1).nonzero().flatten()
+        if unfinished.numel() == 0:
+            return seqs, scores
+        per_call = int(model.max_users_per_call(shape[0], shape[1], K, ref_max_length, limit=4096)) if hasattr(model, "max_users_per_call") \
+            else int(unfinished.numel())
+        width = seqs.shape[1]
+        redo = []
+        for lo in range(0, int(unfinished.numel()), max(per_call, 1)):
+            u = unfinished[lo:lo + per_call]
+            redo.append(model.generate(input_ids=input_ids[u], attention_mask=attention_mask[u], max_length=ref_max_length,
+                                       prefix_allowed_tokens_fn=fn, num_beams=K, num_return_sequences=K, output_scores=True,
+                                       return_dict_in_generate=True, length_penalty=self.length_penalty))
+            width = max(width, redo[-1]["sequences"].shape[1])
+        out_seqs = seqs.new_zeros(B * K, width)  # (pad id 0, as BeamSearchScorer.finalize pads)
+        out_seqs[:, : seqs.shape[1]] = seqs
+        out_scores = scores.clone()
+        rows_of = lambda u: (u[:, None] * K + torch.arange(K, device=u.device)[None, :]).flatten()
+        lo = 0
+        for r in redo:
+            n = r["sequences"].shape[0] // K
+            rows = rows_of(unfinished[lo:lo + n].to(out_seqs.device))
+            out_seqs[rows] = 0
+            out_seqs[rows, : r["sequences"].shape[1]] = r["sequences"].to(out_seqs.device)
+            out_scores[rows.to(out_scores.device)] = r["sequences_scores"].to(out_scores.device)
+            lo += n
+        return out_seqs, out_scores
+
     @staticmethod
     def _merge_batches(parts):
         """Collated batches -> one: passages padded like the Collator pads them (all-zero ids, all-False mask; Collator.py:410-436),
@@ -284,14 +319,18 @@ class BaseRunner:
         trie = gt.Trie(encoded)
         fn = gt.prefix_allowed_tokens_fn(trie)
         lap("candidates_and_trie")
-        # single_runner_gram.py:633-641, hoisted out of the loop: the longest candidate for the "t5_token" / "split" id types.  The
-        # reference passes max_length = 50 for every other id type; the kernels stop at GRAM_MAX_DEC_LEN = 32 and a clamp to the Trie's
-        # depth equals HF's result only when every user has K finished hypotheses by then (otherwise HF keeps decoding -inf beams to
-        # 50 and finalizes differently) -- not implemented rather than approximately right.  The reference's datasets use "split".
-        max_length = max(len(c) for c in encoded)
+        # single_runner_gram.py:629-637, hoisted out of the loop: max_length = the longest candidate for the "t5_token" / "split" id
+        # types, 50 for every other one ("term").  The search runs to the Trie's depth D either way: past it no beam is inside the
+        # Trie, every candidate of every later step is -inf, so a user whose K hypotheses have all finished by D gets from HF at 50
+        # exactly what it gets at D (BeamHypotheses.add refuses a -inf score once the heap is full; is_done turns true on the first
+        # all--inf step).  A user who has FEWER than K finished hypotheses at D is recognisable by a -inf score among its K rows (the
+        # filler beams BeamSearchScorer.finalize adds): HF would have kept decoding that user's -inf beams up to 50 tokens before
+        # finalizing, and such users are scored again with the reference's max_length (`rescore_unfinished` below).
+        longest = max(len(c) for c in encoded)
+        ref_max_length = longest
         if isinstance(candidates[0], str) and _arg(self.args, "item_id_type", "split") not in ("t5_token", "split"):
-            raise NotImplementedError("item_id_type %r decodes with max_length=50 in the reference (single_runner_gram.py:633-641); this "
-                                      "build implements the 't5_token' and 'split' id types" % _arg(self.args, "item_id_type", None))
+            ref_max_length = 50
+        max_length = min(longest, ref_max_length)
         K = self.generate_num
         model = self._generate_model()
         on_device_items = hasattr(model, "sequence_items")
@@ -389,12 +428,16 @@ class BaseRunner:
                         prefix_allowed_tokens_fn=fn, num_beams=K, num_return_sequences=K, output_scores=True,
                         return_dict_in_generate=True, length_penalty=self.length_penalty,
                     )
-                    lap("h2d_and_generate")
-                    total_time += time() - start  # generate() alone, as single_runner_gram.py:640-652 times it (it returns synchronised)
                     B = input_ids.shape[0]
                     seqs = pred["sequences"]
+                    seq_scores = pred["sequences_scores"]
+                    if ref_max_length > max_length:
+                        seqs, seq_scores = self._rescore_unfinished(model, input_ids, attention_mask, seqs, seq_scores, fn, K,
+                                                                    ref_max_length, (n_slots, L))
+                    lap("h2d_and_generate")
+                    total_time += time() - start  # generate() alone, as single_runner_gram.py:640-652 times it (it returns synchronised)
                     items = model.sequence_items(seqs, fn, encoded).cpu().numpy().reshape(B, K) if on_device_items else None
-                    scores = pred["sequences_scores"].detach().cpu().numpy().reshape(B, K)
+                    scores = seq_scores.detach().cpu().numpy().reshape(B, K)
                     need_seqs = items is None or bool((items < 0).any())
                     post_q.put((batch, items, scores, seqs.detach().cpu() if need_seqs else None))
         finally:

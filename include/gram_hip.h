@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GRAM_ABI_VERSION 6
+#define GRAM_ABI_VERSION 7
 
 #define GRAM_E_ARG (-1)       /* bad shape / unsupported size                           */
 #define GRAM_E_WORKSPACE (-2) /* workspace too small (see gram_workspace_bytes)          */
@@ -37,7 +37,8 @@ extern "C" {
                                  |x| <= 65 504) -- use the bfloat16 build (make PIECE=bf16)             */
 
 #define GRAM_MAX_BEAMS 64      /* K <= 64 (reference default 50, headline 20)             */
-#define GRAM_MAX_DEC_LEN 32    /* max_length <= 32 (reference: 8..12)                     */
+#define GRAM_MAX_DEC_LEN 64    /* max_length <= 64 (reference: the longest candidate, 8..12, for the "split" / "t5_token" id
+                                  types, 50 for "term": single_runner_gram.py:629-637); also the row stride of dec_bias_f32 */
 #define GRAM_MAX_PASSAGE_LEN 128 /* L <= 128 (arguments.py:293-298), L % 32 == 0          */
 
 /* ---- GEMM epilogues ------------------------------------------------------------------ */

@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_struct_sizes():
     lib = _lib.load()
-    assert lib.gram_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.gram_abi_version() == _lib.ABI_VERSION == 7
     # field layout sanity (pointer + int32 packing as in the C header)
     assert ctypes.sizeof(_lib.KVBank) == 48
     assert ctypes.sizeof(_lib.Trie) == 40

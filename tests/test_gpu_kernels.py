@@ -425,7 +425,7 @@ def test_dec_self_attn(G):
     inner = H * 64
     g = torch.Generator().manual_seed(21)
     table = torch.randn(32, H, generator=g) * 0.5
-    bias = table[relative_position_bucket(-torch.arange(0, 32), False, 32, 128)].t().contiguous().to(G.DEV)
+    bias = table[relative_position_bucket(-torch.arange(0, _lib.GRAM_MAX_DEC_LEN), False, 32, 128)].t().contiguous().to(G.DEV)
     kc = torch.zeros(Tmax, R, inner, dtype=G.DT, device=G.DEV)
     vc = torch.zeros_like(kc)
     anc = torch.arange(R, dtype=torch.int32).repeat(Tmax, 1).to(G.DEV)

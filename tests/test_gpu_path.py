@@ -236,6 +236,63 @@ def test_generate_vs_oracle(gpu, name, B, N, L, K, n_items, depth):
     _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=SCORE_TOL)
 
 
+def _gen(m, ids, mask, max_length, fn, K):
+    return m.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=max_length, prefix_allowed_tokens_fn=fn,
+                      num_beams=K, num_return_sequences=K, output_scores=True, return_dict_in_generate=True, length_penalty=1.0)
+
+
+def test_long_ids_decode_to_48_tokens(gpu):
+    """max_length past round 3's 32-step limit (GRAM_MAX_DEC_LEN = 64: the reference's "term" id type decodes with max_length = 50,
+    single_runner_gram.py:637): candidates of 40-46 tokens, every step through the self-attention cache, the ancestor table and
+    T5's log-spaced distance buckets, against the oracle."""
+    from gram_amd.utils import generation_trie as gt
+    oc, sd, m = _model(gpu, "tiny", 13)
+    g = torch.Generator().manual_seed(77)
+    B, N, L, K = 2, 2, 32, 4
+    ids, mask = _inputs(g, B, N, L, min(oc.vocab_size, 32100))
+    cands = _random_items(g, 24, 40, 46, 12)  # (12 token values: shared prefixes, so beams branch all the way down)
+    max_length = max(len(c) for c in cands)
+    assert 32 < max_length <= 50
+    ref = O.generate(sd, oc, ids, mask, max_length, O.prefix_allowed_tokens_fn(O.Trie(cands)), K, K, 1.0)
+    out = _gen(m, ids, mask, max_length, gt.prefix_allowed_tokens_fn(gt.Trie(cands)), K)
+    assert out["sequences"].shape == ref["sequences"].shape
+    _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=SCORE_TOL)
+
+
+@pytest.mark.parametrize("kind", ["trie_shallower_than_50", "candidates_longer_than_50"])
+def test_max_length_50(gpu, kind):
+    """What the "term" id type asks of generate() (max_length = 50 whatever the candidates are, single_runner_gram.py:637).
+    (a) A Trie 4-6 tokens deep: the result equals the oracle's at 50 AND the device's own result at the Trie's depth, bit for bit --
+    the runner decodes to the depth (gram_amd/runner/base.py: past it every candidate is -inf and every user already holds K finite
+    hypotheses).  (b) Some candidates longer than 50 tokens: they never finish, BeamSearchScorer.finalize adds the running beams cut
+    at 50 tokens where they beat a finished hypothesis -- same rows, same order, same scores as the oracle."""
+    from gram_amd.utils import generation_trie as gt
+    oc, sd, m = _model(gpu, "tiny", 17)
+    g = torch.Generator().manual_seed(31)
+    B, N, L, K = 3, 2, 32, 4
+    ids, mask = _inputs(g, B, N, L, min(oc.vocab_size, 32100))
+    cands = _random_items(g, 40, 2, 4, 60)
+    if kind == "candidates_longer_than_50":
+        cands = cands[:6] + _random_items(g, 12, 52, 56, 8)
+    depth = max(len(c) for c in cands)
+    fn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
+    ref = O.generate(sd, oc, ids, mask, 50, O.prefix_allowed_tokens_fn(O.Trie(cands)), K, K, 1.0)
+    out = _gen(m, ids, mask, 50, fn, K)
+    sc, rsc = out["sequences_scores"].cpu(), ref["sequences_scores"]
+    assert bool(torch.isfinite(rsc).all()) and bool(torch.isfinite(sc).all())
+    assert out["sequences"].shape == ref["sequences"].shape
+    if kind == "trie_shallower_than_50":
+        _check_generate(oc, sd, out, ref, ids, mask, cands, K, tol=SCORE_TOL)
+        short = _gen(m, ids, mask, depth, fn, K)
+        assert torch.equal(out["sequences"], short["sequences"]) and torch.equal(out["sequences_scores"], short["sequences_scores"])
+    else:
+        assert out["sequences"].shape[1] == 50
+        cut = (ref["sequences"][:, -1] != 0) & (ref["sequences"][:, -1] != 1)
+        assert bool(cut.any()), "no running beam made it into the oracle's top-K: the case does not test the truncation"
+        assert torch.equal(out["sequences"].cpu(), ref["sequences"])
+        assert float((sc - rsc).abs().max()) < SCORE_TOL
+
+
 @pytest.mark.parametrize("kind", ["whole_table_3e5", "outlier_features"])
 def test_large_residual_stream_matches_the_oracle(gpu, kind):
     """T5's residual stream leaves the IEEE-half range in trained checkpoints (the reference's own T5 carries the fp16 clamp for it:

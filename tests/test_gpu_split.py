@@ -239,20 +239,21 @@ def test_split_cross_attn(G, K, S):
     assert e < 10 * tol(G)
 
 
-def test_split_dec_self_attn(G):
+@pytest.mark.parametrize("Tmax,steps", [(10, 5), (64, 64)])  # (GRAM_MAX_DEC_LEN positions: distances up to 63 through T5's log buckets)
+def test_split_dec_self_attn(G, Tmax, steps):
     from gram_amd import _lib
     from gram_amd.model.gram import relative_position_bucket
-    R, H, Tmax = 12, 3, 10
+    R, H = 12, 3
     inner = H * 64
     g = torch.Generator().manual_seed(21)
     table = torch.randn(32, H, generator=g) * 0.5
-    bias = table[relative_position_bucket(-torch.arange(0, 32), False, 32, 128)].t().contiguous().to(G.DEV)
+    bias = table[relative_position_bucket(-torch.arange(0, _lib.GRAM_MAX_DEC_LEN), False, 32, 128)].t().contiguous().to(G.DEV)
     kc = torch.zeros(2, Tmax, R, inner, dtype=G.DT, device=G.DEV)
     vc = torch.zeros_like(kc)
     anc = torch.arange(R, dtype=torch.int32).repeat(Tmax, 1).to(G.DEV)
     cfg = O.OracleConfig(num_heads=H)
     ks, vs = None, None
-    for t in range(5):
+    for t in range(steps):
         qkv32 = (torch.randn(R, 3 * inner, generator=g) * 0.5).to(G.DEV)
         qkv = G.pieces_of(qkv32)
         out = torch.empty(R, 2 * inner, dtype=G.DT, device=G.DEV)  # interleaved

@@ -246,27 +246,6 @@ def test_interleaved_two_piece_layout():
     assert torch.equal(_lib.deinterleave(x), pieces)
 
 
-def test_runner_refuses_id_types_decoded_with_max_length_50():
-    """single_runner_gram.py:633-641 decodes every id type but 't5_token' / 'split' with max_length = 50, which the kernels (32 steps)
-    do not reproduce: refused, not approximated."""
-    from types import SimpleNamespace
-    import pytest
-    from gram_amd.runner import SingleRunnerGRAM
-
-    class Tok:
-        def encode(self, s):
-            return [5, 6, 1]
-
-    args = SimpleNamespace(metrics="hit@1", beam_size=1, item_id_type="other")
-    r = SingleRunnerGRAM(torch.nn.Linear(1, 1), None, Tok(), None, None, None, "cpu", args)
-    loader = []
-
-    class L(list):
-        dataset = SimpleNamespace(all_items=["a b"], dataset="D", task="t")
-    with pytest.raises(NotImplementedError):
-        r._score_loader(L(loader))
-
-
 def test_error_codes_of_the_c_abi_map_to_messages():
     """include/gram_hip.h's GRAM_E_* codes and the text GramHipError carries (the header is the contract: the numbers are read from it)."""
     import re

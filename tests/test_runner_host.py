@@ -204,3 +204,54 @@ def test_flat_trie_from_sequences_equals_the_nested_dict_walk():
     t = gt.Trie([[0, 2, 1]])
     t.add([0, 3, 1])                  # add() after construction is seen by both forms
     assert gt.FlatTrie(t).n_nodes == 6 and t.get([0]) == [2, 3] and len(t) == 2
+
+
+class TermStub(StubModel):
+    """Users whose passage tokens sum to a multiple of 3 have one hypothesis short: decoded to the Trie's depth they get a -inf filler row
+    (start token + padding); decoded with the reference's max_length = 50 the filler is a 50-token row, as HF's would be."""
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    @staticmethod
+    def short(input_ids):
+        return [b for b in range(input_ids.shape[0]) if int(input_ids[b].sum()) % 3 == 0]
+
+    def generate(self, input_ids, attention_mask, max_length, prefix_allowed_tokens_fn, num_beams, **kw):
+        out = StubModel.generate(self, input_ids, attention_mask, max_length, prefix_allowed_tokens_fn, num_beams, **kw)
+        self.users -= input_ids.shape[0] if max_length == 50 else 0
+        self.calls.append((input_ids.shape[0], max_length))
+        for b in self.short(input_ids):
+            row = b * num_beams + num_beams - 1
+            out["sequences"][row] = 0
+            if max_length == 50:
+                out["sequences"][row, 1:] = 7
+            out["sequences_scores"][row] = float("-inf")
+        return out
+
+
+@pytest.mark.parametrize("gpu_batch", [0, 5])
+def test_term_ids_decode_to_the_trie_depth_and_rescore_unfinished_users(tmp_path, gpu_batch):
+    """single_runner_gram.py:629-637: every id type but "t5_token" / "split" is decoded with max_length = 50.  The runner decodes to
+    the Trie's depth and scores again, with 50, exactly the users that come back with a -inf row (fewer than K finished hypotheses:
+    the only users for whom HF's result depends on max_length); their rows are replaced, everyone else's kept."""
+    pred = str(tmp_path / "term.tsv")
+    args = fixture_args(item_id_type="term", eval_batch_size=2, eval_gpu_batch=gpu_batch, save_predictions=True, pred_path=pred)
+    model = TermStub()
+    runner = get_runner("single", model, None, PieceTokenizer(), None, None, None, "cpu", args)
+    loader = runner.testloaders[0]
+    n_short = sum(len(TermStub.short(b["item_text_ids"])) for b in loader)
+    assert 0 < n_short < len(loader.dataset)
+    runner.test_dataset_task(loader)
+    depth = max(len(c) for c in runner.encode_candidates(loader.dataset.all_items))
+    assert depth < 50
+    first = [c for c in model.calls if c[1] == depth]
+    again = [c for c in model.calls if c[1] == 50]
+    assert len(first) + len(again) == len(model.calls) and sum(n for n, _ in first) == len(loader.dataset)
+    assert sum(n for n, _ in again) == n_short
+    rows = open(pred).read().splitlines()[1:1 + len(loader.dataset)]
+    garbage = " ".join(["7"] * 49)
+    assert sum(garbage in r.split("\t")[-2].split("||") for r in rows) == n_short  # the 50-token fillers, decoded like any other row
+    assert sum("-inf" in r.split("\t")[-1] for r in rows) == n_short
+    assert runner.last_results["total"] == len(loader.dataset)
