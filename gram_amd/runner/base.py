@@ -323,9 +323,11 @@ class BaseRunner:
         # types, 50 for every other one ("term").  The search runs to the Trie's depth D either way: past it no beam is inside the
         # Trie, every candidate of every later step is -inf, so a user whose K hypotheses have all finished by D gets from HF at 50
         # exactly what it gets at D (BeamHypotheses.add refuses a -inf score once the heap is full; is_done turns true on the first
-        # all--inf step).  A user who has FEWER than K finished hypotheses at D is recognisable by a -inf score among its K rows (the
-        # filler beams BeamSearchScorer.finalize adds): HF would have kept decoding that user's -inf beams up to 50 tokens before
-        # finalizing, and such users are scored again with the reference's max_length (`rescore_unfinished` below).
+        # all--inf step).  That is every user when each Trie leaf is an EOS: finished hypotheses + beams inside the Trie start at K
+        # (HF's K start beams, all finite) and no step lowers the sum below K.  The guard of that argument: a
+        # user with FEWER than K finished hypotheses at D is recognisable by a -inf score among its K rows (the filler beams
+        # BeamSearchScorer.finalize adds) -- HF would have kept decoding that user's -inf beams up to 50 tokens before finalizing --
+        # and is scored again with the reference's max_length (`_rescore_unfinished`).
         longest = max(len(c) for c in encoded)
         ref_max_length = longest
         if isinstance(candidates[0], str) and _arg(self.args, "item_id_type", "split") not in ("t5_token", "split"):
