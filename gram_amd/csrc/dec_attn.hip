@@ -33,11 +33,11 @@ namespace {
 
 // LDS-DMA through inline asm (see gemm.hip: the builtin makes hipcc wait lgkmcnt(0) in front of every DMA)
 __device__ __forceinline__ void dma16(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
 }
 // the same with the streaming (nontemporal) hint: the bank is read once per step and never again before the next step's sweep
 __device__ __forceinline__ void dma16_nt(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
 }
 #ifndef GRAM_XA_NT
 #define GRAM_XA_NT 1  // bit 0 = K tiles, bit 1 = V^T tiles fetched with the nt hint (A/B build hook; in the bench, one box: 168.8 ms of cross-attention per step without, 163.3 with K only, 165.7 with both)

@@ -69,6 +69,7 @@ constexpr int BN = 128, BK = 64;
 enum { V_DMA_M64 = 31, V_DMA = 1, V_DMA_M256 = 3, V_PP = 22, V_RING_M64 = 33, V_RING_M128 = 34 };  // (ids kept from the variant table of round 1)
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
 int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain)
+int g_pp_entry_delay = 0;  // test hook (gram_debug_set_gemm_variant(2000 + n)): wave group 1 of the ping-pong kernel sleeps n x 512 cycles in the prologue
 int g_pp_clk_on = 0;       // gram_prof_pp_clock_enable: the ping-pong kernel's clock stamps (diagnostic; the product path runs without)
 
 
@@ -549,11 +550,16 @@ int launch_skinny(const void* A, const void* W, int M, int N, int K, int lda, Ep
 // alias every pending ds_read and puts s_waitcnt lgkmcnt(0) in front of it, which serialises the fragment
 // prefetch this kernel is built around.  The asm form is invisible to the waitcnt pass, so the kernel waits
 // for its DMA explicitly (counted s_waitcnt vmcnt) before the barrier that publishes a buffer.
+// `s_nop 3`: invisible to the hazard recognizer as well.  On gfx9 a vector-memory instruction must not read an SGPR within 5 wait states
+// of a VALU instruction writing it (v_readlane / v_readfirstlane: how hipcc reloads a spilled SGPR or makes an address uniform), and
+// hipcc pads its own loads but cannot see the load inside an asm statement: round 4's ISA had `v_readlane_b32 s5, v255, 3` two wait
+// states ahead of `global_load_lds_dword v2, s[4:5]` in four one-piece instantiations (tools/check_isa_hazards.py scans for it now).
+// s_mov (1) + s_nop 3 (4) = 5 wait states between whatever precedes the statement and its load; s_nop 0 alone covers M0 -> LDS-DMA.
 __device__ __forceinline__ void dma16_asm(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
 }
 __device__ __forceinline__ void dma4_asm(uint32_t lds_addr /*wave-uniform*/, uint32_t voff, const char* base /*uniform*/) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1263,6 +1269,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const p16* __restrict__
   // that the 32 tiles an XCD works on at a time cover gm m-tiles x 32/gm n-tiles (fewer distinct A + W panels per round).
   const int gm = (stagger >> 16) & 0xff;
   const bool clk_on = (stagger >> 30) & 1;  // (gram_prof_pp_clock_enable)
+  const int entry_delay = (stagger >> 24) & 0x3f;  // (test hook, 0 in every product launch: see the prologue)
   stagger &= 0xffff;
   auto decode = [&](int tile, int& mt, int& nr) {
     if (gm <= 1) {
@@ -1745,8 +1752,19 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const p16* __restrict__
   advance();
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // W_n0(0) and A_m0(0) have landed
   pp_barrier();
+  // (test hook: group 1 late by entry_delay x 512 cycles -- the timing that exposed the missing barrier below, made deterministic:
+  // tests/test_gpu_kernels.py::test_ping_pong_prologue_survives_a_late_wave_group)
+  if (wr == 1) for (int i = 0; i < entry_delay; ++i) __builtin_amdgcn_s_sleep(8);
   read_w(0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // Every wave holds its W_n0(0) fragments before anyone goes on: group 0's first load slot re-fills that buffer (issue(1, 0) below
+  // = W_n0 of stream k-tile 2).  In the steady state the buffer's readers are a barrier ahead of its re-fill; here, at the entry, group
+  // 0 used to run from its own read straight into that issue, and a wave of group 1 that came late to ITS read found k-tile 2's rows
+  // there: the first tile of a workgroup wrong in group 1's n0 columns by one k-tile's contribution.  The window is the DMA's latency
+  // (microseconds) against a handful of ds_reads, so it never showed -- until a build whose entry block carried a compiler-made
+  // `s_waitcnt vmcnt(0)` between the barrier and the read (a spill reload; round 4's "clock stamps behind a flag" build) spread the
+  // waves of a workgroup over exactly that window (profiles/r04o_*).
+  pp_barrier();
   if (wr == 1) pp_barrier();  // group 1 runs one barrier behind group 0
 
   int tile = slot;
@@ -1802,11 +1820,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const p16* __restrict__
   zero_half(0);
   zero_half(1);
   abl_loop = true;
-  // The two stamps are read UNCONDITIONALLY (two scalar instructions per workgroup and launch); only the atomics at the end are behind
-  // gram_prof_pp_clock_enable.  With the reads themselves inside `if (clk_on)` the fp32-residual instantiations of this kernel returned
-  // wrong tiles intermittently -- flag on or off -- while the kernel without any stamp and the kernel with unconditional ones are both
-  // clean over tens of thousands of randomized runs (tests/stress_gemm_pp*.py, profiles/r04i_pp_clock_flag_race.txt); the difference
-  // is in hipcc's code for the loop entry (spill placement), its cause was not found.  tests/test_gpu_kernels.py runs the screens.
+  // The two stamps are read unconditionally (two scalar instructions per workgroup and launch); the atomics at the end are behind
+  // gram_prof_pp_clock_enable.  (A build with the reads inside `if (clk_on)` returned wrong tiles in round 4: not the stamps -- its
+  // entry block differed, and that exposed the missing barrier of the prologue above.  Fixed there; this form is the measured one.)
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   if constexpr (INSL) {
     const float *rs_cur = nullptr, *rs_prev = nullptr;
@@ -2236,7 +2252,7 @@ int launch_pp(const void* A, const void* W, int M, int N, int K, int lda, EpiArg
     static const int stagger_xcd = getenv("GRAM_GEMM_STAGGER_XCD") ? atoi(getenv("GRAM_GEMM_STAGGER_XCD")) : 0;  // phase = XCD instead of slot & 7
     const int stagger = (stagger_env >= 0 ? stagger_env : g_stagger) | (stagger_xcd ? 0x8000 : 0);
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, X3>), dim3(nblocks), dim3(512), smem, st, (const p16*)A, (const p16*)W, M, N, K, lda,
-                       ep, ntiles, (stagger & 0xffff) | (gm << 16) | (g_pp_clk_on ? 1 << 30 : 0));
+                       ep, ntiles, (stagger & 0xffff) | (gm << 16) | ((g_pp_entry_delay & 0x3f) << 24) | (g_pp_clk_on ? 1 << 30 : 0));
     GRAM_CHECK_LAUNCH();
     return 0;
   }
@@ -2372,6 +2388,10 @@ extern "C" int gram_prof_pp_clock(double* ghz, int reset) {
 extern "C" int gram_gemm_stream_max_m(void) { return g_force_variant < 0 ? stream_max_m() : 0; }
 
 extern "C" int gram_debug_set_gemm_variant(int v) {
+  if (v >= 2000) {  // 2000 + n: wave group 1 of the ping-pong kernel enters n x 512 cycles late (test hook, n <= 63; 2000 = off)
+    g_pp_entry_delay = (v - 2000) & 0x3f;
+    return 0;
+  }
   if (v >= 1000) {  // 1000 + s: set the persistent kernel's start stagger instead
     g_stagger = v - 1000;
     return 0;

@@ -277,9 +277,9 @@ __global__ __launch_bounds__(256) void stream_read_var_kernel(const uint4* __res
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if constexpr (V == 6)
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds0 + par * 8192 + u * 1024), "v"((uint32_t)(lane * 16)), "s"(b + u * 1024) : "memory");
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds0 + par * 8192 + u * 1024), "v"((uint32_t)(lane * 16)), "s"(b + u * 1024) : "memory");
         else
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + par * 8192 + u * 1024), "v"((uint32_t)(lane * 16)), "s"(b + u * 1024) : "memory");
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + par * 8192 + u * 1024), "v"((uint32_t)(lane * 16)), "s"(b + u * 1024) : "memory");
       }
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the previous chunk has landed
       par ^= 1;

@@ -20,6 +20,9 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     lib = _lib.load()
     lib.gram_prof_pp_clock_enable(int(os.environ.get("STAMPS", "0")))  # the diagnostic clock stamps change the kernel's timing: screen both
+    # ENTRY_DELAY=n: wave group 1 enters the prologue n x 512 cycles late (gram_debug_set_gemm_variant(2000 + n): the timing that exposed
+    # the prologue's missing barrier in round 4, made deterministic)
+    lib.gram_debug_set_gemm_variant(2000 + int(os.environ.get("ENTRY_DELAY", "0")))
     rng = random.Random(4321)
     t0, n_cases, n_runs = time.time(), 0, 0
     while time.time() - t0 < budget:

@@ -199,18 +199,21 @@ def test_gemm_64_row_tiles_match_128(G, M, N, K):
 
 
 @pytest.mark.parametrize("script", ["stress_gemm_pp.py", "stress_gemm_pp_x3.py"])
-@pytest.mark.parametrize("stamps", ["0", "1"])
-def test_ping_pong_gemm_race_screen(G, script, stamps):
+@pytest.mark.parametrize("stamps,entry_delay", [("0", "0"), ("1", "0"), ("0", "20")])
+def test_ping_pong_gemm_race_screen(G, script, stamps, entry_delay):
     """The randomized race screens of the persistent ping-pong GEMM (random shapes x epilogues against the 256x128-tile kernel, bit for
-    bit, three runs each) for a few seconds inside the suite, with the diagnostic clock stamps off and on: round 4 shipped, for a few
-    commits, a build whose fp32-residual instantiation returned wrong tiles intermittently (profiles/r04i_pp_clock_flag_race.txt) and
-    only ONE fixed-shape test noticed."""
+    bit, three runs each) for a few seconds inside the suite: with the diagnostic clock stamps off and on, and with wave group 1 entering
+    the prologue ~5 us late.  Round 4 shipped, for a few commits, a build that returned wrong first tiles intermittently
+    (profiles/r04i_pp_clock_flag_race.txt) and only ONE fixed-shape test noticed; its cause was a barrier missing from the prologue
+    since round 2 -- group 0 re-filled the LDS buffer of the first W half-tile while a late wave of group 1 was still to read it
+    (profiles/r04p_pp_prologue_race_root_cause.txt).  The late-group hook makes that timing deterministic: without the barrier every
+    workgroup's first tile is wrong in every run."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tests", script), "8"], cwd=root, capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, STAMPS=stamps))
+                       env=dict(os.environ, STAMPS=stamps, ENTRY_DELAY=entry_delay))
     assert p.returncode == 0 and "MISMATCH" not in p.stdout, p.stdout[-600:] + p.stderr[-600:]
 
 

@@ -54,3 +54,35 @@ def test_scanner_control_flow_and_wait_states(tmp_path):
         "\ts_endpgm\n")
     hits = _scanner().scan_asm(str(p))
     assert [(h[4].split()[0], h[5]) for h in hits] == [("v_add_f32_e32", 7), ("global_store_dword", 2)]
+
+
+def test_scanner_flags_a_valu_written_sgpr_read_by_a_load(tmp_path):
+    """gfx9: a vector-memory instruction may not read an SGPR within 5 wait states of the VALU instruction that wrote it (hipcc pads its
+    own loads; a load inside an asm statement it cannot see).  The round-4 pattern, its padded form, a scalar-ALU rewrite in between and a
+    hazard that arrives through a branch."""
+    p = tmp_path / "k.s"
+    p.write_text(
+        "_Zkern:\n"
+        "\tv_readlane_b32 s4, v255, 2\n"
+        "\tv_lshlrev_b32_e32 v2, 2, v2\n"
+        "\tv_readlane_b32 s5, v255, 3\n"
+        "\ts_mov_b32 m0, s70\n"
+        "\ts_nop 0\n"
+        "\tglobal_load_lds_dword v2, s[4:5]\n"          # s5 two wait states old, s4 four: both too young
+        "\tv_readlane_b32 s9, v255, 5\n"
+        "\ts_mov_b32 m0, s70\n"
+        "\ts_nop 3\n"
+        "\tglobal_load_lds_dwordx4 v3, s[8:9]\n"        # 5 wait states: fine
+        "\tv_readfirstlane_b32 s12, v7\n"
+        "\ts_mov_b32 s12, s20\n"
+        "\tglobal_load_dword v9, v8, s[12:13]\n"        # rewritten by the scalar ALU (interlocked): fine
+        "\tv_readfirstlane_b32 s16, v7\n"
+        "\ts_cbranch_scc1 .LBB0_2\n"
+        "\ts_nop 7\n"
+        ".LBB0_2:\n"
+        "\tbuffer_load_dword v1, v2, s[16:19], 0 offen\n"  # one wait state on the taken path
+        "\ts_endpgm\n")
+    hits = _scanner().scan_asm_sgpr_vmem(str(p))
+    assert [(h[2].split()[0], h[2].split()[1], h[4].split()[0], h[5]) for h in hits] == [
+        ("v_readlane_b32", "s4,", "global_load_lds_dword", 4), ("v_readlane_b32", "s5,", "global_load_lds_dword", 2),
+        ("v_readfirstlane_b32", "s16,", "buffer_load_dword", 1)]

@@ -24,6 +24,9 @@ The packed-fp32 pattern the round-1 scanner looked for (``v_pk_mul_f32 vD, vA, v
 tools/probes/pk_mul_self.hip shows it executes correctly; it differed between the two builds only because the register
 allocation did.
 
+A second scan (scan_kernel_sgpr_vmem, below) looks for vector-memory instructions that read an SGPR fewer than 5 wait states after a
+VALU instruction wrote it -- the one pair hipcc cannot pad when the load sits inside an inline-asm statement.
+
 Usage: tools/check_isa_hazards.py [file.hip | file.s ...]   -> exit status 1 on any hit."""
 import glob
 import os
@@ -141,6 +144,78 @@ def scan_asm(path):
     return hits
 
 
+# ---- second check: a vector-memory instruction reading an SGPR that a VALU instruction wrote fewer than 5 wait states earlier.
+# gfx9 has no interlock for that pair ("VALU writes SGPR -> VMEM reads that SGPR: 5 wait states"); hipcc pads its OWN loads and stores,
+# but a load inside an inline-asm statement (the LDS-DMA of gemm.hip / dec_attn.hip / rowops.hip) is text to it.  Round 4's library had
+# `v_readlane_b32 s5, v255, 3` (a spilled SGPR coming back) two wait states ahead of `global_load_lds_dword v2, s[4:5]` in four
+# one-piece instantiations of the ping-pong GEMM; the asm statements now carry the padding themselves (s_mov m0 + s_nop 3).
+SREG = re.compile(r'\bs(?:(\d+)|\[(\d+):(\d+)\])')
+VMEM_PREFIX = ('global_', 'buffer_', 'scratch_', 'flat_')
+SGPR_VMEM_WAIT = 5
+
+
+def sregs_of(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def scan_kernel_sgpr_vmem(name, ins):
+    """Walks the control-flow graph BACKWARDS from every vector-memory instruction over all paths, up to 5 wait states."""
+    n = len(ins)
+    label_at = {l: i for i, (_, _, labels) in enumerate(ins) for l in labels}
+    pred = [[] for _ in range(n)]
+    for i, (mn, ops, _) in enumerate(ins):
+        if mn == 's_endpgm':
+            continue
+        if mn == 's_branch':
+            t = label_at.get(ops.strip())
+            if t is not None:
+                pred[t].append(i)
+            continue
+        if mn.startswith('s_cbranch'):
+            t = label_at.get(ops.strip().split(',')[-1].strip())
+            if t is not None:
+                pred[t].append(i)
+        if i + 1 < n:
+            pred[i + 1].append(i)
+    hits = []
+    for i, (mn, ops, _) in enumerate(ins):
+        if not mn.startswith(VMEM_PREFIX):
+            continue
+        need = sregs_of(ops)
+        if not need:
+            continue
+        seen, work = set(), [(p, 0, frozenset(need)) for p in pred[i]]
+        while work:
+            j, w, regs = work.pop()
+            if w >= SGPR_VMEM_WAIT or (j, w, regs) in seen:
+                continue
+            seen.add((j, w, regs))
+            m2, o2, _ = ins[j]
+            written = sregs_of(o2.split(',')[0]) if (m2.startswith('v_') or m2.startswith('s_')) and not m2.startswith('s_cmp') else set()
+            if m2.startswith('v_') and (written & regs):
+                hits.append((name, j, f"{m2} {o2}", i, f"{mn} {ops}", w, SGPR_VMEM_WAIT))
+            if written & regs:
+                regs = regs - written  # (a scalar-ALU write is interlocked, a VALU write has been reported: nothing older matters for these)
+                if not regs:
+                    continue
+            for p in pred[j]:
+                work.append((p, w + wait_states(m2, o2), regs))
+    return sorted(set(hits), key=lambda h: (h[3], h[1]))
+
+
+def scan_asm_sgpr_vmem(path):
+    hits = []
+    for name, ins in parse_kernels(path).items():
+        hits += scan_kernel_sgpr_vmem(name, ins)
+    return hits
+
+
 def main(files):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     bad = []
@@ -148,15 +223,15 @@ def main(files):
         for f in files:
             base = os.path.splitext(os.path.basename(f))[0]
             if f.endswith('.s'):
-                bad += [(base,) + h for h in scan_asm(f)]
+                bad += [(base,) + h for h in scan_asm(f) + scan_asm_sgpr_vmem(f)]
                 continue
             subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", f, "-o", os.path.join(tmp, base + ".o"),
                             "-save-temps=obj"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=os.path.dirname(f))
             for asm in glob.glob(os.path.join(tmp, base + "-hip-amdgcn-*.s")):
-                bad += [(base,) + h for h in scan_asm(asm)]
+                bad += [(base,) + h for h in scan_asm(asm) + scan_asm_sgpr_vmem(asm)]
     for b in bad:
         print(f"HAZARD {b[0]} {b[1]}: [{b[2]}] {b[3]}  ->  [{b[4]}] {b[5]}  after {b[6]} wait states (need {b[7]})")
-    print(f"{len(files)} files scanned, {len(bad)} MFMA->VALU/VMEM hazards")
+    print(f"{len(files)} files scanned, {len(bad)} MFMA->VALU/VMEM and VALU-SGPR->VMEM hazards")
     return 1 if bad else 0
 
 
