@@ -230,7 +230,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
     s_lr[tid] = rowpos ? rowpos[row0 + tid] : row0 + tid;  // live-row step: hidden/lse are indexed by compact row
     if (tid == 0) s_isdone = done;
   }
-  __syncthreads();
+  gram_sync();
   if (tid == 0) {
     int acc = 0;
     for (int k = 0; k < K; ++k) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
     s_NC = nc;
     if (acc > nc_max) { st.error[0] = 2; s_C = 0; s_NC = 64; s_pre[K] = 0; }
   }
-  __syncthreads();
+  gram_sync();
   const int C = s_C, NC = s_NC;
   const bool isdone = s_isdone != 0;
 
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
       const int tok = tr.child_tok[s_off[k] + (ci - s_pre[k])];
       keys[ci] = ((unsigned long long)(uint32_t)k << 32) | (unsigned long long)(uint32_t)tok;
     }
-    __syncthreads();
+    gram_sync();
     auto dot = [&](bool act, int lr, int tok, int ci) -> float {
       if (pre) return act ? pre[(size_t)b * nc_max + ci] : 0.f;  // (computed by sparse_logits_kernel: the same function, the same bits)
       return sparse_dot(act, lr, tok, sub, hd, emb, emb32, d, pieces);
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
       }
     }
     if (shared0) {
-      __syncthreads();
+      gram_sync();
       const int cnt0 = s_pre[1];
       const int off0 = cnt0 > 0 ? tr.child_off[st.node[row0]] : 0;
       for (int ci = tid; ci < C; ci += NTHR) {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
         keys[ci] = ((unsigned long long)f2ord(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(k * V + tok));
       }
     }
-    __syncthreads();
+    gram_sync();
   }
   if (!isdone && logits != nullptr) {
     // gather: log_softmax at the allowed tokens + running beam score
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
       }
       keys[ci] = key;
     }
-    __syncthreads();
+    gram_sync();
   }
   if (!isdone) {
     // Non-finite arithmetic is flagged HERE, at its source (GRAM_E_NONFINITE), not at the returned scores: a NaN candidate sorts above
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
           }
         }
       }
-      __syncthreads();
+      gram_sync();
     };
     for (int kk = 2; kk <= top; kk <<= 1)
       for (int j = kk >> 1; j > 0; j >>= 1) stage(NC, kk, j);
@@ -383,13 +383,13 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
           mx[c] = a > b2 ? a : b2;
         }
       }
-      __syncthreads();
+      gram_sync();
 #pragma unroll
       for (int c = 0; c < NMX; ++c) {
         const int o = tid + c * NTHR;
         if (o < half) keys[o] = mx[c];
       }
-      __syncthreads();
+      gram_sync();
       for (int j = P >> 1; j > 0; j >>= 1) stage(half, P, j);  // bitonic blocks -> sorted, directions alternating again
     }
   }
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
       }
       s_edge[rank] = e;
     }
-    __syncthreads();
+    gram_sync();
   }
 
   if (tid == 0) {
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
       }
     }
   }
-  __syncthreads();
+  gram_sync();
 
   // advance sequences / ancestor table / per-row state (read old -> LDS -> write)
   for (int idx = tid; idx < K * T; idx += NTHR) {
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(NTHR) void beam_step_kernel(gram_beam_state_t st, g
     else v = row0 + j;
     new_anc[idx] = v;
   }
-  __syncthreads();
+  gram_sync();
   for (int idx = tid; idx < K * T; idx += NTHR) st.seq[(size_t)row0 * T + idx] = new_seq[idx];
   for (int idx = tid; idx < T * K; idx += NTHR) {
     const int p = idx / K, j = idx - p * K;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void sparse_logits_kernel(gram_beam_state_t st
     s_cnt[tid] = cnt;
     s_lr[tid] = rowpos ? rowpos[row0 + tid] : row0 + tid;
   }
-  __syncthreads();
+  gram_sync();
   if (tid == 0) {
     int acc = 0;
     for (int k = 0; k < K; ++k) {
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void sparse_logits_kernel(gram_beam_state_t st
     }
     s_pre[K] = acc;
   }
-  __syncthreads();
+  gram_sync();
   const bool shared0 = rows_per_user == 1;
   const int nuniq = shared0 ? s_pre[1] : (s_pre[K] <= nc_max ? s_pre[K] : 0);  // (more than nc_max: the search step flags it)
   const int ci = blockIdx.x * 32 + (tid >> 3), sub = tid & 7;
@@ -553,9 +553,9 @@ __global__ __launch_bounds__(1024) void live_rows_kernel(gram_beam_state_t st, g
       const int n = __shfl_up(v, o, 64);
       if (lane >= o) v += n;
     }
-    __syncthreads();  // previous round's s_w / s_tot readers are done
+    gram_sync();  // previous round's s_w / s_tot readers are done
     if (lane == 63) s_w[wave] = v;
-    __syncthreads();
+    gram_sync();
     if (tid == 0) {
       int acc = 0;
       for (int w = 0; w < 16; ++w) {
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(1024) void live_rows_kernel(gram_beam_state_t st, g
       }
       s_tot = acc;
     }
-    __syncthreads();
+    gram_sync();
     return v + s_w[wave];
   };
   int base = 0;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(1024) void live_rows_kernel(gram_beam_state_t st, g
     if (r < R) out.rowpos[r] = live ? pos : -1;
     base += s_tot;
   }
-  __syncthreads();  // rowpos written by this workgroup is visible to it
+  gram_sync();  // rowpos written by this workgroup is visible to it
   int ubase = 0;
   for (int c0 = 0; c0 < B; c0 += 1024) {
     const int b = c0 + tid;

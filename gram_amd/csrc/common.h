@@ -30,6 +30,30 @@ constexpr int GRAM_STREAM_MAX_M_LIMIT = 4096;
 #define GRAM_FMIN (-3.4028234663852886e38f)  // torch.finfo(float32).min, gram_t5_modeling.py:1130-1132
 #define WAVE 64
 
+// ---- workgroup barriers.  Every kernel calls gram_sync() (pp_barrier() in the ping-pong GEMM) instead of __syncthreads(): in the
+// product build it IS __syncthreads().  `make CHAOS=1` (libgram_hip_chaos.so, a diagnostic build that is never shipped) lets a wave
+// sleep up to ~3.5 us behind a barrier now and then, so that the waves of a workgroup run through the region behind it far apart --
+// what a protocol with a barrier missing survives only by timing.  Round 4's prologue race of the ping-pong GEMM is
+// the case in point: three rounds of tests never saw it, this build shows it in the first seconds
+// (tools/r04_gpu_calls/r04r_chaos.sh: the kernel parity tests against the chaos library).
+#ifdef GRAM_CHAOS
+__device__ __forceinline__ void gram_chaos_point() {
+  const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+  const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + blockIdx.x * 7u;
+  const unsigned h = (t ^ (w * 0x9E3779B1u)) * 0x85EBCA6Bu;
+  if ((h >> 29) == 0u) {  // one barrier in eight, per wave
+    const int n = (int)((h >> 20) & 15u);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);  // 512 cycles each
+  }
+}
+#else
+__device__ __forceinline__ void gram_chaos_point() {}
+#endif
+__device__ __forceinline__ void gram_sync() {
+  __syncthreads();
+  gram_chaos_point();
+}
+
 #define GRAM_CHECK_LAUNCH()                       \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \

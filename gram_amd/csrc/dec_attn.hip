@@ -475,7 +475,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     return;
   }
   // merge the waves' partials (the rings are dead once every wave is past its loop)
-  __syncthreads();
+  gram_sync();
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     float lt = l[nt];
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(NW * 64) void cross_attn_kernel(
     for (int mt = 0; mt < 4; ++mt)
       *reinterpret_cast<f32x4*>(sm_o + ((size_t)(wave * NB + beam)) * 64 + 16 * mt + 4 * g) = o[mt][nt];
   }
-  __syncthreads();
+  gram_sync();
   for (int idx = tid; idx < K * 16; idx += NW * 64) {
     const int beam = idx >> 4, d4 = (idx & 15) * 4;
     if constexpr (NW == 2) {

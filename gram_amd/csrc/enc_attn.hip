@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const p16* __restrict__ q
   // Every wave has read its K fragments: the K tiles' LDS is free from here on -- each wave stages its 32 output rows there at the end,
   // so that the rows leave as whole 128 * S-byte segments (below).  (Waves past L left before the first barrier-counted instruction of
   // this kind; s_barrier counts the waves that are still alive.)
-  __syncthreads();
+  gram_sync();
 
   // bias + mask, row maximum over keys for this lane's query column(s)
   float mxq[2], l[2] = {0.f, 0.f};

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const p16* __restrict_
   }
 #pragma unroll
   for (int j = 0; j < MT; ++j) xch[wave][j][lane] = acc1[j];
-  __syncthreads();
+  gram_sync();
   if (wave != 0) return;
   f32x4 acc[4][4];
 #pragma unroll
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(const p16* __restrict_
   auto step = [&](int st, bool steady, p16x8 (&cw)[4], p16x8 (&ca)[4], const p16x8 (&pw)[4], const p16x8 (&pa)[4]) {
     if (steady) wait_vmcnt<(Q * (NS - 2) <= 63 ? Q * (NS - 2) : 63)>();
     else wait_later<Q>(nst - 1 - st);
-    __syncthreads();
+    gram_sync();
     if (consumer) read_frags(cw, ca);
     if (st + NS - 1 < nst) issue();
     if (consumer && st > 0) mfmas(pw, pa);
@@ -933,29 +933,29 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
     int c_slot = 0;
     for (int kt = 0; kt < nkt; ++kt) {
       wait_later<Q>(min(NST - 2, nkt - 1 - kt));
-      __syncthreads();
+      gram_sync();
       if (kt + NST - 1 < nkt) issue();
       compute_tile<TNW, X3>(smem + c_slot * STAGE, smem + c_slot * STAGE + A_BYTES, wm, wn, r16, g, acc);
       c_slot = c_slot + 1 == NST ? 0 : c_slot + 1;
     }
-    __syncthreads();  // (the row-contiguous epilogue re-uses the ring as its patches)
+    gram_sync();  // (the row-contiguous epilogue re-uses the ring as its patches)
   } else {
   load_row_scales(ep, m0 + wm * 64, r16, M, rs4, n0 == 0 && wn == 0);
   if constexpr (NST == 1) {
     for (int kt = 0; kt < nkt; ++kt) {
       dma(kt, 0);
-      __syncthreads();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+      gram_sync();  // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
       compute_tile<TNW, X3>(smem, smem + A_BYTES, wm, wn, r16, g, acc);
-      __syncthreads();
+      gram_sync();
     }
   } else {
     dma(0, 0);
-    __syncthreads();
+    gram_sync();
     for (int kt = 0; kt < nkt; ++kt) {
       const int st = kt & 1;
       if (kt + 1 < nkt) dma(kt + 1, st ^ 1);
       compute_tile<TNW, X3>(smem + st * STAGE, smem + st * STAGE + A_BYTES, wm, wn, r16, g, acc);
-      __syncthreads();  // drains DMA(kt+1) and fences the reads of stage st
+      gram_sync();  // drains DMA(kt+1) and fences the reads of stage st
     }
   }
   }
@@ -994,7 +994,10 @@ __global__ __launch_bounds__(WM * 128, (NST >= 3 ? 1 : TNW == 8 ? 2 : (NST == 1 
 // order, rows through LDS) and V^T tiles (PP_KV_V: operands the other way round, direct 8-B stores).  One instantiation
 // with both code paths spills accumulators (256 VGPRs); each half alone does not.
 constexpr int PP_KV_K = 100, PP_KV_V = 101;
-__device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+__device__ __forceinline__ void pp_barrier() {
+  asm volatile("s_barrier" ::: "memory");
+  gram_chaos_point();  // (nothing in the product build: common.h)
+}
 
 // Store the wave's output rows of m-tiles j0, j0+1 (32 rows x 64 columns) through its LDS patch as whole
 // 128-B (bf16) / 256-B (fp32) row segments, 16 rows per pass.  Runs inside a LOAD slot of the ping-pong

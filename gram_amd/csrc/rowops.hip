@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ 
     sm[tid >> 6] = wm;
     ss[tid >> 6] = s;
   }
-  __syncthreads();
+  gram_sync();
   if (tid == 0) {
     float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
     float S = 0.f;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void stream_read_var_kernel(const uint4* __res
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + u * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void*)(&buf[wave][u][0]), 16, 0, 0);
     }
-    __syncthreads();
+    gram_sync();
     a.x = *reinterpret_cast<const uint32_t*>(&buf[wave][0][lane * 4]);
   }
   if constexpr (V == 6 || V == 7) {  // LDS-DMA through inline asm, with the nt hint (6) / without (7); 16 KiB per wave in flight, counted waits

@@ -36,14 +36,12 @@ tend_a = '      if (wr == 0) pp_barrier();\n      if constexpr ((GRAM_PP_ABL & 1
 tend_b = '      zero_half(0);\n      zero_half(1);\n      pp_barrier();\n      if (more && wr == 1) pp_barrier();'
 assert bad0.count(tend_a) == 1 and bad0.count(tend_b) == 1
 full = 'asm volatile("s_waitcnt vmcnt(0)" ::: "memory");'
-# the proof: hold group 1 back for ~5 us between the prologue's first barrier and its read of W_n0(0) -- without the barrier that read finds
-# group 0's re-fill of the buffer (wrong first tiles, every run), with it nothing changes
-rd = '  pp_barrier();\n  read_w(0, 0);\n'
-delay = '  pp_barrier();\n  if (wr == 1) for (int i = 0; i < 20; ++i) __builtin_amdgcn_s_sleep(8);\n  read_w(0, 0);\n'
-assert src.count(rd) == 1 and fixed.count(rd) == 1
+# the proof: run `nofix` (the round-4 prologue) with ENTRY_DELAY=20 (the kernel's test hook holds group 1 back ~5 us between the prologue's
+# first barrier and its read of W_n0(0)): that read finds group 0's re-fill of the buffer -- wrong first tiles, every run; with the barrier
+# (the product library) nothing changes
 variants = {
-    'delay': src.replace(rd, delay),
-    'fixed_delay': fixed.replace(rd, delay),
+    'nofix_chaos': src,          # the round-4 kernel (no prologue barrier), compiled with -DGRAM_CHAOS=1: does the chaos build find the race by itself?
+    'nofix': src,
     'fixed_bad': fixed.replace(good, cond),                                          # conditional stamp reads + the prologue barrier: clean
     'fixed_bad_nop0': nop0(fixed.replace(good, cond)),
     'bad_drain_entry': bad0.replace(entry, full),                                   # only the prologue's counted wait a full drain
@@ -61,7 +59,8 @@ for k, v in variants.items():
 P
 for f in $V/src/gemm_*.hip; do
   n=$(basename $f .hip); n=${n#gemm_}
-  ( cp $f $C/_variant_$n.hip && $HIPCC --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -c $C/_variant_$n.hip -o $V/gemm_$n.o && rm -f $C/_variant_$n.hip &&
+  X=""; case $n in *_chaos) X="-DGRAM_CHAOS=1";; esac
+  ( cp $f $C/_variant_$n.hip && $HIPCC --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function $X -c $C/_variant_$n.hip -o $V/gemm_$n.o && rm -f $C/_variant_$n.hip &&
     $HIPCC --offload-arch=gfx950 -shared -fPIC $V/gemm_$n.o $C/build/rowops.o $C/build/enc_attn.o $C/build/dec_attn.o $C/build/beam.o $C/build/generate.o $C/build/prof.o $C/build/aliases.o -o $V/libgram_hip_$n.so && echo built $n ) &
 done
 wait
