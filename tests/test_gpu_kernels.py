@@ -217,6 +217,23 @@ def test_ping_pong_gemm_race_screen(G, script, stamps, entry_delay):
     assert p.returncode == 0 and "MISMATCH" not in p.stdout, p.stdout[-600:] + p.stderr[-600:]
 
 
+@pytest.mark.parametrize("script", ["stress_gemm_pp.py", "stress_gemm_pp_x3.py"])
+def test_race_screen_on_the_chaos_build(G, script):
+    """The same screens against libgram_hip_chaos.so (make CHAOS=1; __graft_entry__.build() makes it): the product sources with a random
+    sleep of up to ~3.5 us behind every workgroup barrier, one time in eight per wave -- a missing barrier that timing hides in the product
+    build (round 4's prologue race: 3 774 randomized cases clean) fails there in the first case (profiles/r04r_chaos_build.txt)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "gram_amd", "csrc", "libgram_hip_chaos.so")
+    if not os.path.exists(lib):
+        pytest.skip("libgram_hip_chaos.so not built (make -C gram_amd/csrc CHAOS=1)")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", script), "8"], cwd=root, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GRAM_LIB=lib, STAMPS="0", ENTRY_DELAY="0"))
+    assert p.returncode == 0 and "MISMATCH" not in p.stdout, p.stdout[-600:] + p.stderr[-600:]
+
+
 def test_f16_alias_is_the_same_entry_point(G):
     """gram_gemm_f16 (gram_hip.h: the alias a maintainer should bind) runs gram_gemm_bf16's kernel in the IEEE-half build."""
     if not G.F16:
