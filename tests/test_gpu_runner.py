@@ -92,6 +92,51 @@ def test_rebatched_runner_equals_one_user_per_call(tmp_path):
     assert ta == tb == tc
 
 
+class _At50:
+    """A model view whose generate() always runs with the reference's max_length = 50 for the "term" id type (single_runner_gram.py:637),
+    whatever the runner passes."""
+
+    def __init__(self, m):
+        self._m = m
+        self.lengths = []
+
+    def __getattr__(self, name):
+        return getattr(self._m, name)
+
+    def generate(self, *a, **kw):
+        self.lengths.append(kw["max_length"])
+        kw["max_length"] = 50
+        return self._m.generate(*a, **kw)
+
+
+def test_term_id_type_decoded_to_the_trie_depth_equals_max_length_50(tmp_path):
+    """`--item_id_type term`: the reference decodes with max_length = 50; the runner decodes to the candidate Trie's depth.  Same hit ranks,
+    sums and preds TSV, byte for byte, as the same runner over a model that decodes to 50 tokens."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import gram_amd
+    from gram_amd.runner import get_runner
+    ckpt = str(tmp_path / "model_rec_best.pt")
+    _checkpoint(ckpt)
+    res = []
+    for tag in ("depth", "fifty"):
+        pred = str(tmp_path / f"{tag}.tsv")
+        model = gram_amd.create_model("gram", _cfg()).to(DEV)
+        runner = get_runner("single", model, None, PieceTokenizer(), None, None, None, DEV,
+                            fixture_args(item_id_type="term", save_predictions=True, pred_path=pred, eval_batch_size=3))
+        view = _At50(model)
+        if tag == "fifty":
+            runner._generate_model = lambda v=view: v
+        runner.test(ckpt)
+        res.append((runner.last_results, open(pred).read(), view.lengths))
+    (a, ta, _), (b, tb, lens) = res
+    depth = max(len(c) for c in runner.encode_candidates(runner.testloaders[0].dataset.all_items))
+    assert lens and all(x == depth for x in lens) and depth < 50  # (what the runner asked for; the view decoded to 50 instead)
+    assert a["total"] == b["total"] == 12
+    assert a["hit_ranks"].tolist() == b["hit_ranks"].tolist() and np.array_equal(a["sums"], b["sums"])
+    assert ta == tb and "-inf" not in ta
+
+
 class _NoItems:
     """A model view without `sequence_items`: the runner then decodes every generated row, like the reference."""
 
