@@ -15,13 +15,25 @@ from gram_amd import _lib  # noqa: E402
 from tests import gpu_util as G  # noqa: E402
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+def main(budget=None, stamps=None, entry_delay=None):
+    """-> 0 (all bit-identical) / 1 (a mismatch, printed).  Callable in-process (tests/test_gpu_kernels.py) or as a script."""
+    budget = float(budget if budget is not None else sys.argv[1] if len(sys.argv) > 1 else 120.0)
+    stamps = int(stamps if stamps is not None else os.environ.get("STAMPS", "0"))
+    entry_delay = int(entry_delay if entry_delay is not None else os.environ.get("ENTRY_DELAY", "0"))
     lib = _lib.load()
-    lib.gram_prof_pp_clock_enable(int(os.environ.get("STAMPS", "0")))  # the diagnostic clock stamps change the kernel's timing: screen both
+    try:
+        return _screen(lib, budget, stamps, entry_delay)
+    finally:  # leave the library as the product path runs it
+        lib.gram_debug_set_gemm_variant(-1)
+        lib.gram_debug_set_gemm_variant(2000)
+        lib.gram_prof_pp_clock_enable(0)
+
+
+def _screen(lib, budget, stamps, entry_delay):
+    lib.gram_prof_pp_clock_enable(stamps)  # the diagnostic clock stamps change the kernel's timing: screen both
     # ENTRY_DELAY=n: wave group 1 enters the prologue n x 512 cycles late (gram_debug_set_gemm_variant(2000 + n): the timing that exposed
     # the prologue's missing barrier in round 4, made deterministic)
-    lib.gram_debug_set_gemm_variant(2000 + int(os.environ.get("ENTRY_DELAY", "0")))
+    lib.gram_debug_set_gemm_variant(2000 + entry_delay)
     rng = random.Random(1234)
     t0, n_cases, n_runs = time.time(), 0, 0
     while time.time() - t0 < budget:
@@ -64,12 +76,12 @@ def main():
                 if not torch.equal(a, b):
                     bad = (a.float() - b.float()).abs()
                     print(f"MISMATCH M={M} N={N} K={K} epi={epi} fused={fused} rep={rep}: {int((bad > 0).sum())} elements, max {float(bad.max())}")
-                    sys.exit(1)
+                    return 1
         n_cases += 1
         del A, W, ref, got
-    lib.gram_debug_set_gemm_variant(-1)
     print(f"ok: {n_cases} random cases, {n_runs} ping-pong runs, all bit-identical to the reference kernel")
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -198,9 +198,9 @@ def test_gemm_64_row_tiles_match_128(G, M, N, K):
             assert torch.equal(outs[1][key], outs[v][key]), (v, key)
 
 
-@pytest.mark.parametrize("script", ["stress_gemm_pp.py", "stress_gemm_pp_x3.py"])
-@pytest.mark.parametrize("stamps,entry_delay", [("0", "0"), ("1", "0"), ("0", "20")])
-def test_ping_pong_gemm_race_screen(G, script, stamps, entry_delay):
+@pytest.mark.parametrize("script", ["stress_gemm_pp", "stress_gemm_pp_x3"])
+@pytest.mark.parametrize("stamps,entry_delay", [(0, 0), (1, 0), (0, 20)])
+def test_ping_pong_gemm_race_screen(G, script, stamps, entry_delay, capsys):
     """The randomized race screens of the persistent ping-pong GEMM (random shapes x epilogues against the 256x128-tile kernel, bit for
     bit, three runs each) for a few seconds inside the suite: with the diagnostic clock stamps off and on, and with wave group 1 entering
     the prologue ~5 us late.  Round 4 shipped, for a few commits, a build that returned wrong first tiles intermittently
@@ -208,20 +208,18 @@ def test_ping_pong_gemm_race_screen(G, script, stamps, entry_delay):
     since round 2 -- group 0 re-filled the LDS buffer of the first W half-tile while a late wave of group 1 was still to read it
     (profiles/r04p_pp_prologue_race_root_cause.txt).  The late-group hook makes that timing deterministic: without the barrier every
     workgroup's first tile is wrong in every run."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tests", script), "8"], cwd=root, capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, STAMPS=stamps, ENTRY_DELAY=entry_delay))
-    assert p.returncode == 0 and "MISMATCH" not in p.stdout, p.stdout[-600:] + p.stderr[-600:]
+    import importlib
+    mod = importlib.import_module("tests." + script)
+    rc = mod.main(budget=6, stamps=stamps, entry_delay=entry_delay)
+    out = capsys.readouterr().out
+    assert rc == 0 and "MISMATCH" not in out, out[-600:]
 
 
-@pytest.mark.parametrize("script", ["stress_gemm_pp.py", "stress_gemm_pp_x3.py"])
-def test_race_screen_on_the_chaos_build(G, script):
-    """The same screens against libgram_hip_chaos.so (make CHAOS=1; __graft_entry__.build() makes it): the product sources with a random
-    sleep of up to ~3.5 us behind every workgroup barrier, one time in eight per wave -- a missing barrier that timing hides in the product
-    build (round 4's prologue race: 3 774 randomized cases clean) fails there in the first case (profiles/r04r_chaos_build.txt)."""
+def test_race_screens_on_the_chaos_build(G):
+    """The same screens against libgram_hip_chaos.so (make CHAOS=1; __graft_entry__.build() makes it), in a process of its own (the
+    library is chosen at import): the product sources with a random sleep of up to ~3.5 us behind every workgroup barrier, one time in
+    eight per wave -- a missing barrier that timing hides in the product build (round 4's prologue race: 3 774 randomized cases clean)
+    fails there in the first case (profiles/r04r_chaos_build.txt)."""
     import os
     import subprocess
     import sys
@@ -229,9 +227,10 @@ def test_race_screen_on_the_chaos_build(G, script):
     lib = os.path.join(root, "gram_amd", "csrc", "libgram_hip_chaos.so")
     if not os.path.exists(lib):
         pytest.skip("libgram_hip_chaos.so not built (make -C gram_amd/csrc CHAOS=1)")
-    p = subprocess.run([sys.executable, os.path.join(root, "tests", script), "8"], cwd=root, capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, GRAM_LIB=lib, STAMPS="0", ENTRY_DELAY="0"))
-    assert p.returncode == 0 and "MISMATCH" not in p.stdout, p.stdout[-600:] + p.stderr[-600:]
+    code = ("import sys; from tests import stress_gemm_pp as a, stress_gemm_pp_x3 as b; "
+            "sys.exit(a.main(budget=6, stamps=0, entry_delay=0) or b.main(budget=6, stamps=0, entry_delay=0))")
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300, env=dict(os.environ, GRAM_LIB=lib))
+    assert p.returncode == 0 and "MISMATCH" not in p.stdout and p.stdout.count("bit-identical") == 2, p.stdout[-600:] + p.stderr[-600:]
 
 
 def test_f16_alias_is_the_same_entry_point(G):
