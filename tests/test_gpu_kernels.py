@@ -2,7 +2,6 @@
 of the same op on the same seeded inputs.  Integer outputs are compared bit-exactly; floating-point
 ones within the bf16-operand / fp32-accumulate tolerance stated at each assert."""
 import ctypes as C
-import math
 
 import numpy as np
 import pytest

@@ -7,7 +7,6 @@ results are compared within stated tolerances (each <= 10x the deviation observe
 and the *integer* results (which items, in which order) through tolerance-aware checks: a returned sequence must be a
 Trie member, its score must match the oracle's score of that same sequence, and any disagreement in membership/order
 must be between candidates whose oracle scores are closer than the tolerance."""
-import ctypes as C
 import os
 
 import numpy as np

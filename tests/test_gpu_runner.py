@@ -4,8 +4,6 @@ tests/golden/dataset_fixture: the runner builds its own dataset / collator / loa
 user through gram_generate and writes the preds TSV.  The distributed runner is run as 5 ranks sharing the one test GPU
 (gloo for the collectives; RCCL needs a GPU per rank) on a user count the world size does not divide, and must
 reproduce the single runner's result."""
-import os
-import tempfile
 
 import numpy as np
 import pytest

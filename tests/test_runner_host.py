@@ -1,8 +1,6 @@
 """CPU: the host half of the drop-in runner at the headline rate (SURVEY.md §8d second metric, §8f N2):
 re-batching whatever --eval_batch_size is, the per-item token-row table of the collator, the vectorised separator strip and
 metrics, item indices instead of decoded rows.  Every fast form is compared with the slow form it replaces."""
-import os
-from types import SimpleNamespace
 
 import numpy as np
 import pytest
@@ -12,7 +10,7 @@ from gram_amd.processor import collator as col
 from gram_amd.runner import get_runner
 from gram_amd.utils import evaluate
 from gram_amd.utils import generation_trie as gt
-from tests.test_runner_loaders import K, PieceTokenizer, StubModel, fixture_args
+from tests.test_runner_loaders import PieceTokenizer, StubModel, fixture_args
 
 
 def _strip_rows_loop(ids, mask, limit):
