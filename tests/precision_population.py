@@ -23,6 +23,13 @@ back (gain / F on those dimensions, and all gains x the factor by which the outl
 IEEE-half range for large F, its rms is dominated by the outliers, and the information sits in dimensions far below the rms: the case
 the per-row power-of-two factors of the 16-bit copy exist for.
 
+``--train-steps S`` runs S Adam steps on the weights first (plain torch fp32 autograd through the oracle's own functions, on the GPU): a
+synthetic retrieval task -- the gold item of a user is one of 256 items, announced by that item's marker token scattered over the user's
+passages; the decoder is taught (teacher forcing, cross-entropy) to spell the item's id pieces -- so that the comparison runs on weights
+that gradient descent has shaped (attention that looks for particular keys, logits that commit to a piece) instead of a random
+initialisation or a rescaled one.  No trained GRAM checkpoint exists offline; this is the closest population that can be made here.  The
+evaluation users are drawn from the task's distribution (markers included), over the full candidate Trie.
+
 ``--sharpen F`` multiplies every attention q projection by F: at T5's random init the attention logits are ~N(0,1)
 and every query averages ~140 keys, which washes the encoder out of the scores (all users get nearly the same
 beams); F = 4 gives peaky attention (a few keys per query), i.e. scores that depend on the passages as a trained
@@ -75,7 +82,79 @@ def add_outlier_features(sd, oc, F):
         done.add(id(v))
 
 
-def build(backbone, seed, sharpen, dev, outliers=0.0):
+MARKER_COPIES = 12
+
+
+def marker_range(vmax, n_cands):
+    """(first marker token, number of marked items): the top of the vocabulary below `vmax`, 256 items for a real vocabulary."""
+    n = max(1, min(256, n_cands, (vmax - 2) // 4))
+    return vmax - n, n
+
+
+def plant_markers(ids, mask, gold, g, base):
+    """In place: MARKER_COPIES copies of token base + gold[b] at random valid positions of user b's passages (not the last position)."""
+    B, N, L = ids.shape
+    for b in range(B):
+        valid = torch.nonzero(mask[b, :, : L - 1].reshape(-1)).flatten()
+        if valid.numel() == 0:
+            continue
+        pick = valid[torch.randint(0, valid.numel(), (MARKER_COPIES,), generator=g)]
+        ids[b].view(-1)[(pick // (L - 1)) * L + pick % (L - 1)] = base + int(gold[b])
+
+
+def train_briefly(sd, oc, cands, steps, N, L, vmax, seed, dev, log, batch=32, lr=5e-4):
+    """See --train-steps in the module docstring.  sd: the state dict ON THE DEVICE (aliases aliased); trained in place.
+    Returns (mean loss of the first 10 steps, of the last 10)."""
+    from oracle import gram_oracle as O
+    uniq = {}
+    for k, v in sd.items():
+        uniq.setdefault(id(v), v)
+    params = [v.requires_grad_(True) for v in uniq.values()]
+    opt = torch.optim.Adam(params, lr=lr)
+    g = torch.Generator().manual_seed(seed + 7)
+    base, n_items = marker_range(vmax, len(cands))
+    items = cands[:n_items]
+    T = max(len(c) for c in items)
+    losses = []
+    for step in range(steps):
+        gold = torch.randint(0, len(items), (batch,), generator=g)
+        ids = torch.randint(2, base, (batch, N, L), generator=g)
+        ids[:, :, -1] = 1
+        mask = torch.ones(batch, N, L, dtype=torch.bool)
+        plant_markers(ids, mask, gold, g, base)
+        tgt = torch.full((batch, T), -100, dtype=torch.long)
+        dec_in = torch.zeros(batch, T - 1, dtype=torch.long)
+        for b, gi in enumerate(gold.tolist()):
+            seq = items[gi]
+            tgt[b, : len(seq) - 1] = torch.tensor(seq[1:])
+            dec_in[b, : len(seq) - 1] = torch.tensor(seq[:-1])
+        ids_d, mask_d, tgt, dec_in = ids.to(dev), mask.to(dev), tgt.to(dev), dec_in.to(dev)
+        enc = O.encode_fused(sd, oc, ids_d, mask_d)
+        ext = (1.0 - mask_d.reshape(batch, 1, 1, N * L).to(torch.float32)) * O.FMIN
+        st = O.DecodeState(cross=O.cross_kv(sd, oc, enc), enc_mask_ext=ext, rows_per_bank=1)
+        loss = 0.0
+        n_tok = int((tgt[:, : T - 1] >= 0).sum())
+        for t in range(T - 1):
+            logits = O.decoder_step(sd, oc, dec_in[:, t], st)
+            loss = loss + torch.nn.functional.cross_entropy(logits, tgt[:, t], ignore_index=-100, reduction="sum")
+        loss = loss / n_tok
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        lr_t = lr * min(1.0, (step + 1) / 20)
+        for grp in opt.param_groups:
+            grp["lr"] = lr_t
+        opt.step()
+        losses.append(float(loss.detach()))
+        if step % 50 == 0 or step == steps - 1:
+            log(f"[precision] training step {step + 1}/{steps}: loss {losses[-1]:.3f}")
+    for v in params:
+        v.requires_grad_(False)
+    k = min(10, len(losses))
+    return sum(losses[:k]) / k, sum(losses[-k:]) / k
+
+
+def build(backbone, seed, sharpen, dev, outliers=0.0, train=None):
     import gram_amd
     from oracle import gram_oracle as O
 
@@ -102,16 +181,22 @@ def build(backbone, seed, sharpen, dev, outliers=0.0):
             uniq.setdefault(id(v), v.clone())
             sd[k] = uniq[id(v)]
         add_outlier_features(sd, oc, outliers)
-    model = gram_amd.create_model("gram", gc)
-    model.load_state_dict(sd)
-    model = model.to(dev).eval()
     sd_dev = {}
     seen = {}
     for k, v in sd.items():  # keep the aliases aliased on the device
         if id(v) not in seen:
             seen[id(v)] = v.to(dev)
         sd_dev[k] = seen[id(v)]
-    return oc, sd_dev, model
+    trained = None
+    if train:  # (steps, cands, N, L, vmax, log): a few hundred optimiser steps on the device copy, then the model gets THOSE weights
+        steps, cands, N, L, vmax, log = train
+        trained = train_briefly(sd_dev, oc, cands, steps, N, L, vmax, seed, dev, log)
+        back = {}
+        sd = {k: back.setdefault(id(v), v.detach().cpu()) for k, v in sd_dev.items()}
+    model = gram_amd.create_model("gram", gc)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    return oc, sd_dev, model, trained
 
 
 def compare(ref_seqs, ref_scores, out_seqs, out_scores, B, K, user0, acc):
@@ -187,11 +272,10 @@ def sweep_modes(base, pieces):
 
 
 def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("f16x3",), seed=2023, sharpen=1.0, N=3, L=128, K=20,
-        dev="cuda:0", log=print, n_items=0, ragged=False, outliers=0.0):
+        dev="cuda:0", log=print, n_items=0, ragged=False, outliers=0.0, train_steps=0):
     from gram_amd.utils import generation_trie as gt
     from oracle import gram_oracle as O
 
-    oc, sd, model = build(backbone, seed, sharpen, dev, outliers)
     if backbone == "tiny":
         g0 = torch.Generator().manual_seed(5)
         cands = sorted({tuple([0] + torch.randint(2, 60, (3,), generator=g0).tolist() + [1]) for _ in range(n_items or 400)})
@@ -201,6 +285,7 @@ def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("f16
         z = np.load(os.path.join(ROOT, "tests", "golden", "tries.npz"))
         cands = [[int(x) for x in row if x >= 0] for row in z[f"{dataset}_cands"]]
         vmax = 32100
+    oc, sd, model, trained = build(backbone, seed, sharpen, dev, outliers, (train_steps, cands, N, L, vmax, log) if train_steps else None)
     max_length = max(len(c) for c in cands)
     dfn = gt.prefix_allowed_tokens_fn(gt.Trie(cands))
     ofn = O.prefix_allowed_tokens_fn(O.Trie(cands))
@@ -221,6 +306,10 @@ def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("f16
             mask = torch.arange(L)[None, None, :] < lens[:, :, None]
             ids[torch.arange(B)[:, None], torch.arange(N)[None, :], (lens - 1).clamp(min=0)] = 1
             ids[~mask] = 0
+        if train_steps:  # users of the task the weights were trained on
+            base, n_marked = marker_range(vmax, len(cands))
+            ids[(ids >= base) & mask] = 2
+            plant_markers(ids, mask, torch.randint(0, n_marked, (B,), generator=g), g, base)
         t0 = time.perf_counter()
         ref = O.generate(sd, oc, ids.to(dev), mask.to(dev), max_length, ofn, K, K, 1.0)
         torch.cuda.synchronize()
@@ -247,7 +336,10 @@ def run(users=4096, chunk=256, backbone="t5-base", dataset="Beauty", modes=("f16
     model.set_stage_pieces(None)
     return {
         "population": {"backbone": backbone, "dataset": dataset, "items": len(cands), "users": users, "N": N, "L": L, "K": K,
-                       "seed": seed, "q_sharpen": sharpen, "ragged_masks": bool(ragged), "outlier_features_x": outliers, "gold_rank": "reference rank (user index mod 10)",
+                       "seed": seed, "q_sharpen": sharpen, "ragged_masks": bool(ragged), "outlier_features_x": outliers,
+                       "trained": ({"adam_steps": train_steps, "loss_first10": round(trained[0], 4), "loss_last10": round(trained[1], 4),
+                                    "task": f"{marker_range(vmax, len(cands))[1]} items announced by marker tokens, teacher-forced cross-entropy on the id pieces"}
+                                   if trained else None), "gold_rank": "reference rank (user index mod 10)",
                        "reference": "oracle/gram_oracle.py run with torch fp32 tensors on the GPU (rocBLAS fp32), HF-4.26 search on the host"},
         "modes": {m: summarise(a) for m, a in accs.items()},
     }
@@ -264,6 +356,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2023)
     ap.add_argument("--sharpen", type=float, default=1.0)
     ap.add_argument("--outliers", type=float, default=0.0, help="outlier features F times the ordinary ones (a trained T5's residual stream)")
+    ap.add_argument("--train-steps", type=int, default=0, help="Adam steps on a synthetic retrieval task before the comparison (a TRAINED population)")
     ap.add_argument("--beams", type=int, default=20)
     ap.add_argument("--out", default="")
     ap.add_argument("--sweep", default="", help="BASE mode: every stage at fewer pieces with the rest at BASE (per-stage sensitivity)")
@@ -272,7 +365,7 @@ def main():
     if a.sweep:
         import gram_amd
         modes = tuple(sweep_modes(a.sweep, gram_amd.GRAM._PIECES[a.sweep]))
-    res = run(a.users, a.chunk, a.backbone, a.dataset, modes, a.seed, a.sharpen, K=a.beams, ragged=a.ragged, outliers=a.outliers)
+    res = run(a.users, a.chunk, a.backbone, a.dataset, modes, a.seed, a.sharpen, K=a.beams, ragged=a.ragged, outliers=a.outliers, train_steps=a.train_steps)
     txt = json.dumps(res, indent=1)
     print(txt)
     if a.out:
