@@ -69,7 +69,7 @@ constexpr int BN = 128, BK = 64;
 enum { V_DMA_M64 = 31, V_DMA = 1, V_DMA_M256 = 3, V_PP = 22, V_RING_M64 = 33, V_RING_M128 = 34 };  // (ids kept from the variant table of round 1)
 int g_force_variant = -1;  // tuning hook (gram_debug_set_gemm_variant)
 int g_stagger = 0;         // start stagger of the persistent kernel (measured: no gain)
-int g_pp_entry_delay = 0;  // test hook (gram_debug_set_gemm_variant(2000 + n)): wave group 1 of the ping-pong kernel sleeps n x 512 cycles in the prologue
+int g_pp_entry_delay = 0;  // test hook (gram_debug_set_gemm_variant(2000 + n)): in the CHAOS build wave group 1 of the ping-pong kernel sleeps n x 512 cycles in the prologue
 int g_pp_clk_on = 0;       // gram_prof_pp_clock_enable: the ping-pong kernel's clock stamps (diagnostic; the product path runs without)
 
 
@@ -1272,7 +1272,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const p16* __restrict__
   // that the 32 tiles an XCD works on at a time cover gm m-tiles x 32/gm n-tiles (fewer distinct A + W panels per round).
   const int gm = (stagger >> 16) & 0xff;
   const bool clk_on = (stagger >> 30) & 1;  // (gram_prof_pp_clock_enable)
-  const int entry_delay = (stagger >> 24) & 0x3f;  // (test hook, 0 in every product launch: see the prologue)
+#ifdef GRAM_CHAOS
+  const int entry_delay = (stagger >> 24) & 0x3f;  // (test hook of the chaos build, see the prologue; the product build has no such code)
+#endif
   stagger &= 0xffff;
   auto decode = [&](int tile, int& mt, int& nr) {
     if (gm <= 1) {
@@ -1755,9 +1757,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const p16* __restrict__
   advance();
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // W_n0(0) and A_m0(0) have landed
   pp_barrier();
-  // (test hook: group 1 late by entry_delay x 512 cycles -- the timing that exposed the missing barrier below, made deterministic:
-  // tests/test_gpu_kernels.py::test_ping_pong_prologue_survives_a_late_wave_group)
+#ifdef GRAM_CHAOS
+  // test hook (make CHAOS=1 only): group 1 late by entry_delay x 512 cycles -- the timing that exposed the missing barrier below, made
+  // deterministic (gram_debug_set_gemm_variant(2000 + n); tests/test_gpu_kernels.py::test_race_screens_on_the_chaos_build)
   if (wr == 1) for (int i = 0; i < entry_delay; ++i) __builtin_amdgcn_s_sleep(8);
+#endif
   read_w(0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // Every wave holds its W_n0(0) fragments before anyone goes on: group 0's first load slot re-fills that buffer (issue(1, 0) below
@@ -2391,7 +2395,7 @@ extern "C" int gram_prof_pp_clock(double* ghz, int reset) {
 extern "C" int gram_gemm_stream_max_m(void) { return g_force_variant < 0 ? stream_max_m() : 0; }
 
 extern "C" int gram_debug_set_gemm_variant(int v) {
-  if (v >= 2000) {  // 2000 + n: wave group 1 of the ping-pong kernel enters n x 512 cycles late (test hook, n <= 63; 2000 = off)
+  if (v >= 2000) {  // 2000 + n: wave group 1 of the ping-pong kernel enters n x 512 cycles late (test hook of the chaos build, n <= 63; 2000 = off)
     g_pp_entry_delay = (v - 2000) & 0x3f;
     return 0;
   }

@@ -498,8 +498,9 @@ int gram_prof_pp_clock(double* ghz, int reset);
 
 /* Tuning hook: force a GEMM staging variant (0 = register-staged double buffer, 1 = LDS-DMA
  * single buffer, -1 = automatic per problem size).  Used by tests/bench_gemm.py.  1000 + s: start stagger of the persistent kernel.
- * 2000 + n (n <= 63; 2000 = off): TEST hook -- wave group 1 of the persistent ping-pong kernel enters its prologue n x 512 cycles
- * late, which turns a round-4 race of that prologue (fixed) into a deterministic test. */
+ * 2000 + n (n <= 63; 2000 = off): TEST hook, honoured by the chaos build only (make CHAOS=1; the product kernels carry no test code) --
+ * wave group 1 of the persistent ping-pong kernel enters its prologue n x 512 cycles late, which turns a round-4 race of that prologue
+ * (fixed) into a deterministic test. */
 int gram_debug_set_gemm_variant(int variant);
 
 /* Calibration probe (bench.py): one streaming read of `bytes` (16-B aligned) through every CU; nothing is

@@ -32,8 +32,8 @@ def main(budget=None, stamps=None, entry_delay=None):
 
 def _screen(lib, budget, stamps, entry_delay):
     lib.gram_prof_pp_clock_enable(stamps)  # the diagnostic clock stamps change the kernel's timing: screen both
-    # ENTRY_DELAY=n: wave group 1 enters the prologue n x 512 cycles late (gram_debug_set_gemm_variant(2000 + n): the timing that exposed
-    # the prologue's missing barrier in round 4, made deterministic)
+    # ENTRY_DELAY=n: wave group 1 enters the prologue n x 512 cycles late (gram_debug_set_gemm_variant(2000 + n); honoured by the chaos build,
+    # GRAM_LIB=.../libgram_hip_chaos.so: the timing that exposed the prologue's missing barrier in round 4, made deterministic)
     lib.gram_debug_set_gemm_variant(2000 + entry_delay)
     rng = random.Random(4321)
     t0, n_cases, n_runs = time.time(), 0, 0

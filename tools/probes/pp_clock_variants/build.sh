@@ -36,7 +36,7 @@ tend_a = '      if (wr == 0) pp_barrier();\n      if constexpr ((GRAM_PP_ABL & 1
 tend_b = '      zero_half(0);\n      zero_half(1);\n      pp_barrier();\n      if (more && wr == 1) pp_barrier();'
 assert bad0.count(tend_a) == 1 and bad0.count(tend_b) == 1
 full = 'asm volatile("s_waitcnt vmcnt(0)" ::: "memory");'
-# the proof: run `nofix` (the round-4 prologue) with ENTRY_DELAY=20 (the kernel's test hook holds group 1 back ~5 us between the prologue's
+# the proof: run `nofix_chaos` (the round-4 prologue, -DGRAM_CHAOS=1) with ENTRY_DELAY=20 (the chaos build's test hook holds group 1 back ~5 us between the prologue's
 # first barrier and its read of W_n0(0)): that read finds group 0's re-fill of the buffer -- wrong first tiles, every run; with the barrier
 # (the product library) nothing changes
 variants = {
