@@ -207,7 +207,7 @@ def test_ping_pong_gemm_race_screen(G, script, stamps, capsys):
     while a late wave of group 1 was still to read it (profiles/r04p_pp_prologue_race_root_cause.txt)."""
     import importlib
     mod = importlib.import_module("tests." + script)
-    rc = mod.main(budget=6, stamps=stamps, entry_delay=0)
+    rc = mod.main(budget=4, stamps=stamps, entry_delay=0)
     out = capsys.readouterr().out
     assert rc == 0 and "MISMATCH" not in out, out[-600:]
 
@@ -227,7 +227,7 @@ def test_race_screens_on_the_chaos_build(G):
     if not os.path.exists(lib):
         pytest.skip("libgram_hip_chaos.so not built (make -C gram_amd/csrc CHAOS=1)")
     code = ("import sys; from tests import stress_gemm_pp as a, stress_gemm_pp_x3 as b; "
-            "sys.exit(a.main(budget=6, stamps=0, entry_delay=0) or b.main(budget=6, stamps=0, entry_delay=20))")
+            "sys.exit(a.main(budget=5, stamps=0, entry_delay=0) or b.main(budget=5, stamps=0, entry_delay=20))")
     p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300, env=dict(os.environ, GRAM_LIB=lib))
     assert p.returncode == 0 and "MISMATCH" not in p.stdout and p.stdout.count("bit-identical") == 2, p.stdout[-600:] + p.stderr[-600:]
 

@@ -13,7 +13,7 @@ resolves the 1e-4 bound it asserts (two flipped users would already fail it).
   ragged      Collator-shaped masks: valid lengths U[32, 128], fully padded passages (4 096 users: zero flips required)
 
   trained     weights shaped by gradient descent: Adam steps on a synthetic retrieval task through the oracle's own functions (plain torch
-              fp32 autograd on the GPU), then users of that task.  In the suite on T5-small (300 steps, 8 192 users); on T5-base, 1 200
+              fp32 autograd on the GPU), then users of that task.  In the suite on T5-small (200 steps, 4 096 users); on T5-base, 1 200
               steps: profiles/r04v_precision_trained_t5base.json (1 rank flip at the rank-10 line, Recall@5 / NDCG@5 unchanged)
 
 Parity on a trained GRAM checkpoint is unpinned: none exists offline.
@@ -64,13 +64,13 @@ def test_ragged_mask_population():
 
 
 def test_briefly_trained_population():
-    """8 192 users (the fp32 reference's host-side search is most of this test's time): ONE user across the rank-5 line is 1.22e-4 here, so
-    the assertion allows exactly that one; the 16 384-user measurements of this population (T5-small here in round 4: 2 rank flips, none
-    across the line; T5-base, 1 200 steps: profiles/r04v_precision_trained_t5base.json) are inside the 1e-4 bound."""
-    m = _run(users=8192, backbone="t5-small", train_steps=300)
+    """4 096 users after 200 steps (the fp32 reference's host-side search is most of this test's time): ONE user across the rank-5 line is
+    2.4e-4 here, so the assertion allows exactly that one; the 16 384-user measurements of this population (T5-small, 300 steps: 2 rank
+    flips, none across the line; T5-base, 1 200 steps: profiles/r04v_precision_trained_t5base.json) are inside the 1e-4 bound."""
+    m = _run(users=4096, backbone="t5-small", train_steps=200)
     tr = m["population"]["trained"]
     assert tr["loss_last10"] < 0.5 * tr["loss_first10"], tr  # the optimiser did shape the weights
-    assert m["abs_delta"]["hit@5"] <= 1.25e-4 and m["abs_delta"]["ndcg@5"] <= BOUND, m["abs_delta"]
+    assert m["abs_delta"]["hit@5"] <= 2.5e-4 and m["abs_delta"]["ndcg@5"] <= BOUND, m["abs_delta"]
     assert m["max_abs_score_dev"] < 1e-3
 
 
