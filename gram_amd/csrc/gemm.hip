@@ -1829,7 +1829,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(const p16* __restrict__
   abl_loop = true;
   // The two stamps are read unconditionally (two scalar instructions per workgroup and launch); the atomics at the end are behind
   // gram_prof_pp_clock_enable.  (A build with the reads inside `if (clk_on)` returned wrong tiles in round 4: not the stamps -- its
-  // entry block differed, and that exposed the missing barrier of the prologue above.  Fixed there; this form is the measured one.)
+  // entry block differed, and that exposed the missing barrier of the prologue above.  Fixed there; with the race gone the conditional
+  // form is correct but 0.4-0.5 % slower in the bench (two more SGPR spills and a scratch reload behind a vmcnt(0) in the entry block:
+  // profiles/r04x_stamp_reads_ab.txt), so the two scalar reads stay unconditional.)
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   if constexpr (INSL) {
     const float *rs_cur = nullptr, *rs_prev = nullptr;
